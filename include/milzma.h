@@ -1,0 +1,207 @@
+/*
+ * milzma.h -- C ABI of the MI355X-native batched LZMA / LZMA2 / XZ decoder.
+ *
+ * Drop-in boundary for the decode hot path of gendx/lzma-rs (reference paths are
+ * relative to the reference repository root):
+ *
+ *   src/decode/rangecoder.rs   RangeDecoder, BitTree, LenDecoder
+ *   src/decode/lzma.rs:164-593 DecoderState (literal / match / rep state machine)
+ *   src/decode/lzbuffer.rs     LzCircularBuffer / LzAccumBuffer (LZ77 window + output)
+ *
+ * The reference has no FFI layer; the seam this ABI replaces is
+ * DecoderState::process(&mut LZB, &mut RangeDecoder) (src/decode/lzma.rs:255-261) as it is
+ * called from LzmaDecoder::decompress (src/decode/lzma.rs:635-648) and
+ * Lzma2Decoder::decompress (src/decode/lzma2.rs:52-82), plus the three public entry points
+ * of src/lib.rs:44-105 for callers that want whole-file semantics.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature (a HIP stream is
+ * passed as an opaque `void *`).  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer of the crate would add to bind these.
+ */
+#ifndef MILZMA_H
+#define MILZMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MILZMA_ABI_VERSION 1
+
+/* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
+enum {
+  MILZMA_OK = 0,
+  MILZMA_IO_ERROR = 1,         /* Error::IoError(io::Error)       "io error: ..."          */
+  MILZMA_HEADER_TOO_SHORT = 2, /* Error::HeaderTooShort(io::Error) "header too short: ..."  */
+  MILZMA_LZMA_ERROR = 3,       /* Error::LzmaError(String)        "lzma error: ..."        */
+  MILZMA_XZ_ERROR = 4,         /* Error::XzError(String)          "xz error: ..."          */
+  MILZMA_INFRA_ERROR = 5       /* not a reference error: HIP failure, bad argument, no GPU */
+};
+
+/* ---- decode units: one independent serial decode job = one wavefront -------------------- */
+
+/* unit kinds */
+#define MILZMA_KIND_RAW_LZMA 0u /* LzmaDecoder::decompress: input starts at the range coder's first byte */
+#define MILZMA_KIND_LZMA2 1u    /* Lzma2Decoder::decompress: input starts at an LZMA2 status byte          */
+
+#define MILZMA_SIZE_UNKNOWN UINT64_MAX /* unpacked_size: Option::None => end-of-stream marker mode */
+#define MILZMA_NO_LIMIT UINT64_MAX     /* memlimit: Option::None                                    */
+
+/* Largest input / output slice a single unit may span (positions are 32-bit on the device). */
+#define MILZMA_MAX_UNIT_BYTES 0xFFFFFF00ull
+
+typedef struct milzma_unit {
+  uint64_t in_off;        /* offset of the unit's compressed bytes inside the input base        */
+  uint64_t in_len;        /* bytes the unit's reader can see (its EOF)                           */
+  uint64_t out_off;       /* offset of the unit's output slice inside the output base            */
+  uint64_t out_cap;       /* bytes the unit may write                                            */
+  uint64_t unpacked_size; /* RAW_LZMA: LzmaParams.unpacked_size (src/decode/lzma.rs:70-77)        */
+  uint64_t memlimit;      /* RAW_LZMA: Options.memlimit (src/decode/options.rs:10-14)             */
+  uint32_t dict_size;     /* RAW_LZMA: LzmaParams.dict_size                                       */
+  uint8_t lc, lp, pb;     /* RAW_LZMA: LzmaProperties (src/decode/lzma.rs:43-58)                  */
+  uint8_t kind;           /* MILZMA_KIND_*                                                        */
+} milzma_unit;
+
+/* Per-unit status: one code per error site on the hot path. `a`/`b`
+ * are the integers the reference formats into its message. */
+enum {
+  MILZMA_ST_OK = 0,
+  MILZMA_ST_RC_INIT = 1,          /* lzma.rs:643-644 / lzma2.rs:190-191: range decoder init hit EOF   */
+  MILZMA_ST_INPUT_EOF = 2,        /* rangecoder.rs:64: normalize() hit EOF -> IoError(UnexpectedEof)    */
+  MILZMA_ST_MATCH_DIST_DICT = 3,  /* lzbuffer.rs:241-245  "Match distance {a} is beyond dictionary size {b}" */
+  MILZMA_ST_MATCH_DIST_OUT = 4,   /* lzbuffer.rs:246-251,98-105 "Match distance {a} is beyond output size {b}" */
+  MILZMA_ST_LZ_DIST_DICT = 5,     /* lzbuffer.rs:274-278  "LZ distance {a} is beyond dictionary size {b}" */
+  MILZMA_ST_LZ_DIST_OUT = 6,      /* lzbuffer.rs:279-285,125-133 "LZ distance {a} is beyond output size {b}" */
+  MILZMA_ST_MEMLIMIT = 7,         /* lzbuffer.rs:210-217  "exceeded memory limit of {a}"                */
+  MILZMA_ST_MARKER_TRAILING = 8,  /* lzma.rs:378-380      "Found end-of-stream marker but more bytes are available" */
+  MILZMA_ST_SIZE_MISMATCH = 9,    /* lzma.rs:513-521      "Expected unpacked size of {a} but decompressed to {b}" */
+  /* LZMA2 packet layer (src/decode/lzma2.rs), walked by the wavefront itself */
+  MILZMA_ST_L2_STATUS_EOF = 16,     /* :60-62   "LZMA2 expected new status: {io}"                        */
+  MILZMA_ST_L2_INVALID_STATUS = 17, /* :94-99   "LZMA2 invalid status {a}, must be 0, 1, 2 or >= 128"    */
+  MILZMA_ST_L2_UNPACKED_EOF = 18,   /* :128-130,204-206 "LZMA2 expected unpacked size: {io}"             */
+  MILZMA_ST_L2_PACKED_EOF = 19,     /* :133-135 "LZMA2 expected packed size: {io}"                       */
+  MILZMA_ST_L2_PROPS_EOF = 20,      /* :153-155 "LZMA2 expected new properties: {io}"                    */
+  MILZMA_ST_L2_PROPS_INVALID = 21,  /* :158-163 "LZMA2 invalid properties: {a} must be < 225"            */
+  MILZMA_ST_L2_LCLP = 22,           /* :170-175 "LZMA2 invalid properties: lc + lp ({a} + {b}) must be <= 4" */
+  MILZMA_ST_L2_STORED_EOF = 23,     /* :219-225 "LZMA2 expected {a} uncompressed bytes: {io}"            */
+  /* not reference errors: conditions of this implementation, resolved by the host layer */
+  MILZMA_ST_OUT_FULL = 32,   /* out_cap reached before the stream ended (grow the slice and retry)     */
+  MILZMA_ST_NEED_LCLP = 33,  /* unit needs a literal table for lc+lp = {a} larger than its launch class */
+  MILZMA_ST_BAD_UNIT = 34    /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
+};
+
+typedef struct milzma_result {
+  uint32_t status;      /* MILZMA_ST_*                                                               */
+  uint32_t chunks;      /* LZMA2: packets walked (diagnostic)                                          */
+  uint64_t out_len;     /* bytes appended to the unit's output slice                                   */
+  uint64_t out_flushed; /* of those, how many the reference's sink would have received at return:
+                           all of them on success; on error only what had been flushed before
+                           (ring wraps for RAW_LZMA, dictionary resets for LZMA2)                     */
+  uint64_t in_consumed; /* reader position at return, relative to in_off                               */
+  uint64_t err_a, err_b;
+} milzma_result;
+
+typedef struct milzma_ctx milzma_ctx;
+
+/* Creates a context bound to HIP device `device` (ordinal). Fails (MILZMA_INFRA_ERROR) when no
+ * GPU / HIP runtime is usable: there is no CPU fallback in this library. */
+int milzma_create(int device, milzma_ctx **out_ctx);
+void milzma_destroy(milzma_ctx *ctx);
+/* Text of the last MILZMA_INFRA_ERROR on this context (or on creation when ctx == NULL). */
+const char *milzma_last_error(const milzma_ctx *ctx);
+
+/* The batch entry point: replaces n calls of DecoderState::process (src/decode/lzma.rs:255-261)
+ * behind LzmaDecoder::decompress / Lzma2Decoder::decompress.
+ *   units        host array of n descriptors
+ *   d_in, d_out  DEVICE pointers: compressed input base / output base (HBM resident)
+ *   results      host array of n results
+ *   hip_stream   hipStream_t to launch on (NULL = default stream); the call returns after the
+ *                results have been copied back (it synchronises that stream)
+ * Returns MILZMA_OK or MILZMA_INFRA_ERROR; per-unit failures never fail the batch. */
+int milzma_decode_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_in,
+                        void *d_out, milzma_result *results, void *hip_stream);
+
+/* Same, with host-resident input / output: the library stages both through device buffers it
+ * owns (PCIe-inclusive path). */
+int milzma_decode_units_host(milzma_ctx *ctx, const milzma_unit *units, uint32_t n,
+                             const void *h_in, size_t in_bytes, void *h_out, size_t out_bytes,
+                             milzma_result *results);
+
+/* Duration in ms of the decode kernels of the most recent milzma_decode_units* call, measured
+ * with HIP events on the launch stream, and how many kernel launches that was. */
+float milzma_last_kernel_ms(const milzma_ctx *ctx, uint32_t *launches);
+
+/* Renders a unit result as the reference would: returns the error kind (MILZMA_OK ...
+ * MILZMA_XZ_ERROR) and writes the full Display string (src/error.rs:28-36) into msg. */
+int milzma_result_message(const milzma_result *res, uint32_t unit_kind, char *msg, size_t msg_cap);
+
+/* ---- whole-file entry points: src/lib.rs:44-105 ------------------------------------------ */
+
+/* decompress::UnpackedSize (src/decode/options.rs:22-43) */
+enum {
+  MILZMA_READ_FROM_HEADER = 0,
+  MILZMA_READ_HEADER_BUT_USE_PROVIDED = 1,
+  MILZMA_USE_PROVIDED = 2
+};
+
+/* decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only. */
+typedef struct milzma_options {
+  int32_t unpacked_size_mode;
+  int32_t provided_is_some;
+  uint64_t provided;
+  int32_t memlimit_is_some;
+  int32_t reserved;
+  uint64_t memlimit;
+} milzma_options;
+
+/* What the call did to the caller's reader and writer. `data` holds exactly the bytes the
+ * reference would have written to its `W: io::Write` (also on error); free with milzma_free. */
+typedef struct milzma_output {
+  uint8_t *data;
+  size_t len;
+  size_t in_consumed; /* how far the reference would have advanced its `R: io::BufRead` */
+  int32_t kind;       /* MILZMA_OK or the error kind */
+  char msg[388];      /* Display string of the error */
+} milzma_output;
+
+void milzma_default_options(milzma_options *opt);
+void milzma_free(void *p);
+
+/* lzma_decompress_with_options (src/lib.rs:52-60); opt == NULL => Options::default() */
+int milzma_lzma_decompress(milzma_ctx *ctx, const uint8_t *in, size_t in_len,
+                           const milzma_options *opt, milzma_output *out);
+/* lzma2_decompress (src/lib.rs:83-88) */
+int milzma_lzma2_decompress(milzma_ctx *ctx, const uint8_t *in, size_t in_len, milzma_output *out);
+/* xz_decompress (src/lib.rs:100-105) */
+int milzma_xz_decompress(milzma_ctx *ctx, const uint8_t *in, size_t in_len, milzma_output *out);
+
+/* Many complete files in one go: every stream (.lzma) / every block of every file (.xz) becomes
+ * one unit of a single launch. outs[i] is filled exactly as the single-file call would. */
+int milzma_lzma_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                                 const size_t *in_lens, const milzma_options *opt,
+                                 milzma_output *outs);
+int milzma_lzma2_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                                  const size_t *in_lens, milzma_output *outs);
+int milzma_xz_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                               const size_t *in_lens, milzma_output *outs);
+
+/* ---- host-side parsing, usable without a GPU (and tested without one) -------------------- */
+
+/* LzmaParams::read_header (src/decode/lzma.rs:96-161): fills lc/lp/pb/dict_size/unpacked_size/
+ * memlimit/kind of `unit` and sets *header_len to the bytes consumed. Returns the error kind and
+ * message in `out` (kind/msg only) on failure. */
+int milzma_lzma_read_header(const uint8_t *in, size_t in_len, const milzma_options *opt,
+                            milzma_unit *unit, size_t *header_len, milzma_output *out);
+
+/* CRC-32 (ISO-HDLC) and CRC-64/XZ as used by the XZ layer (src/xz/crc.rs:1-4). */
+uint32_t milzma_crc32(const uint8_t *p, size_t n);
+uint64_t milzma_crc64(const uint8_t *p, size_t n);
+
+uint32_t milzma_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILZMA_H */
