@@ -1,0 +1,413 @@
+"""lzma_rs_amd -- MI355X-native batched LZMA / LZMA2 / XZ decoding.
+
+Python face of the C ABI in include/milzma.h (ctypes, no torch types).  It mirrors the
+decode surface of the reference crate gendx/lzma-rs (src/lib.rs:44-105):
+
+    lzma_decompress(input, output)                      src/lib.rs:44-49
+    lzma_decompress_with_options(input, output, opts)   src/lib.rs:52-60
+    lzma2_decompress(input, output)                     src/lib.rs:83-88
+    xz_decompress(input, output)                        src/lib.rs:100-105
+    decompress.Options / decompress.UnpackedSize        src/decode/options.rs
+    error.Error {IoError, HeaderTooShort, LzmaError, XzError}   src/error.rs
+
+`input` is bytes-like or a binary file object (the reference's `R: io::BufRead`); `output` is a
+binary file object or bytearray (its `W: io::Write`).  On error the bytes the reference would
+already have pushed to `W` are still written before the exception is raised, and a seekable input
+is left where the reference would have left its reader.
+
+All decoding runs in HIP kernels on the GPU; importing this package never touches the GPU, and
+there is no CPU fallback: creating a Context without an MI355X raises InfraError.
+"""
+import ctypes
+import os
+import sys
+
+from . import workloads  # noqa: F401  (synthetic stream generator, host-only)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmilzma.so")
+
+# ---- error kinds / statuses (include/milzma.h) ---------------------------------------------
+OK, IO_ERROR, HEADER_TOO_SHORT, LZMA_ERROR, XZ_ERROR, INFRA_ERROR = range(6)
+KIND_RAW_LZMA, KIND_LZMA2 = 0, 1
+SIZE_UNKNOWN = 0xFFFFFFFFFFFFFFFF
+NO_LIMIT = 0xFFFFFFFFFFFFFFFF
+ST_OK = 0
+ST_OUT_FULL = 32
+
+
+class Error(Exception):
+    """error::Error (src/error.rs:8-17); str() is the reference's Display string."""
+    kind = None
+
+    def __init__(self, msg, written=0, in_consumed=0):
+        super().__init__(msg)
+        self.written = written
+        self.in_consumed = in_consumed
+
+
+class IoError(Error):
+    kind = IO_ERROR
+
+
+class HeaderTooShort(Error):
+    kind = HEADER_TOO_SHORT
+
+
+class LzmaError(Error):
+    kind = LZMA_ERROR
+
+
+class XzError(Error):
+    kind = XZ_ERROR
+
+
+class InfraError(Error):
+    """Not a reference error: no GPU, HIP failure, bad argument."""
+    kind = INFRA_ERROR
+
+
+_ERRORS = {IO_ERROR: IoError, HEADER_TOO_SHORT: HeaderTooShort, LZMA_ERROR: LzmaError,
+           XZ_ERROR: XzError, INFRA_ERROR: InfraError}
+
+
+class UnpackedSize:
+    """decompress::UnpackedSize (src/decode/options.rs:22-43)."""
+    READ_FROM_HEADER = 0
+    READ_HEADER_BUT_USE_PROVIDED = 1
+    USE_PROVIDED = 2
+
+    def __init__(self, mode=0, provided=None):
+        self.mode = mode
+        self.provided = provided
+
+    @classmethod
+    def ReadFromHeader(cls):
+        return cls(cls.READ_FROM_HEADER)
+
+    @classmethod
+    def ReadHeaderButUseProvided(cls, x):
+        return cls(cls.READ_HEADER_BUT_USE_PROVIDED, x)
+
+    @classmethod
+    def UseProvided(cls, x):
+        return cls(cls.USE_PROVIDED, x)
+
+
+class Options:
+    """decompress::Options (src/decode/options.rs:3-20)."""
+
+    def __init__(self, unpacked_size=None, memlimit=None, allow_incomplete=False):
+        self.unpacked_size = unpacked_size or UnpackedSize.ReadFromHeader()
+        self.memlimit = memlimit
+        self.allow_incomplete = allow_incomplete  # stream API only; no effect here (as in the crate)
+
+
+# ---- ctypes mirror of the ABI structs --------------------------------------------------------
+class Unit(ctypes.Structure):
+    _fields_ = [("in_off", ctypes.c_uint64), ("in_len", ctypes.c_uint64),
+                ("out_off", ctypes.c_uint64), ("out_cap", ctypes.c_uint64),
+                ("unpacked_size", ctypes.c_uint64), ("memlimit", ctypes.c_uint64),
+                ("dict_size", ctypes.c_uint32), ("lc", ctypes.c_uint8), ("lp", ctypes.c_uint8),
+                ("pb", ctypes.c_uint8), ("kind", ctypes.c_uint8)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_uint32), ("chunks", ctypes.c_uint32),
+                ("out_len", ctypes.c_uint64), ("out_flushed", ctypes.c_uint64),
+                ("in_consumed", ctypes.c_uint64), ("err_a", ctypes.c_uint64),
+                ("err_b", ctypes.c_uint64)]
+
+
+class _COptions(ctypes.Structure):
+    _fields_ = [("unpacked_size_mode", ctypes.c_int32), ("provided_is_some", ctypes.c_int32),
+                ("provided", ctypes.c_uint64), ("memlimit_is_some", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("memlimit", ctypes.c_uint64)]
+
+
+class _COutput(ctypes.Structure):
+    _fields_ = [("data", ctypes.POINTER(ctypes.c_uint8)), ("len", ctypes.c_size_t),
+                ("in_consumed", ctypes.c_size_t), ("kind", ctypes.c_int32),
+                ("msg", ctypes.c_char * 388)]
+
+
+EXPORTS = [
+    "milzma_abi_version", "milzma_create", "milzma_destroy", "milzma_last_error",
+    "milzma_decode_units", "milzma_decode_units_host", "milzma_last_kernel_ms",
+    "milzma_result_message", "milzma_default_options", "milzma_free",
+    "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
+    "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
+    "milzma_lzma_read_header", "milzma_crc32", "milzma_crc64",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libmilzma.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the
+    # whole process (same SONAME), and torch cannot initialise on top of the system one.  Load
+    # torch first so that device tensors and this library share one runtime.
+    if "torch" not in sys.modules and not os.environ.get("MILZMA_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    if not os.path.exists(_LIB_PATH):
+        raise InfraError("libmilzma.so is not built: run `make -C lzma_rs_amd/csrc` "
+                         "(or __graft_entry__.build()); there is no fallback path")
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, u32, u64, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
+    L.milzma_abi_version.restype = u32
+    L.milzma_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.milzma_destroy.argtypes = [vp]
+    L.milzma_last_error.restype = ctypes.c_char_p
+    L.milzma_last_error.argtypes = [vp]
+    L.milzma_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result), vp]
+    L.milzma_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz,
+                                           ctypes.POINTER(Result)]
+    L.milzma_last_kernel_ms.restype = ctypes.c_float
+    L.milzma_last_kernel_ms.argtypes = [vp, ctypes.POINTER(u32)]
+    L.milzma_result_message.argtypes = [ctypes.POINTER(Result), u32, ctypes.c_char_p, sz]
+    L.milzma_free.argtypes = [vp]
+    L.milzma_lzma_decompress.argtypes = [vp, vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(_COutput)]
+    L.milzma_lzma2_decompress.argtypes = [vp, vp, sz, ctypes.POINTER(_COutput)]
+    L.milzma_xz_decompress.argtypes = [vp, vp, sz, ctypes.POINTER(_COutput)]
+    L.milzma_lzma_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                               ctypes.POINTER(_COptions), ctypes.POINTER(_COutput)]
+    L.milzma_lzma2_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                                ctypes.POINTER(_COutput)]
+    L.milzma_xz_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                             ctypes.POINTER(_COutput)]
+    L.milzma_lzma_read_header.argtypes = [vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(Unit),
+                                          ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
+    L.milzma_crc32.restype = u32
+    L.milzma_crc32.argtypes = [vp, sz]
+    L.milzma_crc64.restype = u64
+    L.milzma_crc64.argtypes = [vp, sz]
+    _lib = L
+    return L
+
+
+def _c_options(options):
+    o = _COptions()
+    if options is None:
+        return o
+    us = options.unpacked_size
+    o.unpacked_size_mode = us.mode
+    o.provided_is_some = 0 if us.provided is None else 1
+    o.provided = 0 if us.provided is None else us.provided
+    o.memlimit_is_some = 0 if options.memlimit is None else 1
+    o.memlimit = 0 if options.memlimit is None else options.memlimit
+    return o
+
+
+class Decoded:
+    """Outcome of one whole-file call: bytes for the writer, reader advance, error (or None)."""
+
+    def __init__(self, cout):
+        self.data = ctypes.string_at(cout.data, cout.len) if cout.len else b""
+        self.in_consumed = cout.in_consumed
+        self.kind = cout.kind
+        self.msg = cout.msg.decode("utf-8", "replace")
+        if cout.data:
+            lib().milzma_free(ctypes.cast(cout.data, ctypes.c_void_p))
+
+    @property
+    def ok(self):
+        return self.kind == OK
+
+    def error(self):
+        if self.kind == OK:
+            return None
+        return _ERRORS[self.kind](self.msg, written=len(self.data), in_consumed=self.in_consumed)
+
+    def __repr__(self):
+        return "Decoded(kind=%d, msg=%r, len=%d, in_consumed=%d)" % (
+            self.kind, self.msg, len(self.data), self.in_consumed)
+
+
+def _as_buffer(data):
+    """bytes-like -> (ctypes pointer, length, keepalive)."""
+    if isinstance(data, (bytes, bytearray)):
+        buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if len(data) else ctypes.c_char_p(b"")
+        return ctypes.cast(buf, ctypes.c_void_p), len(data), buf
+    mv = memoryview(data).cast("B")
+    buf = (ctypes.c_char * len(mv)).from_buffer_copy(mv) if len(mv) else ctypes.c_char_p(b"")
+    return ctypes.cast(buf, ctypes.c_void_p), len(mv), buf
+
+
+class Context:
+    """milzma_ctx bound to one GPU.  Raises InfraError when no MI355X / HIP runtime is usable."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        L = lib()
+        if L.milzma_create(device, ctypes.byref(self._h)) != OK:
+            raise InfraError("milzma_create failed: " + (L.milzma_last_error(None) or b"").decode())
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().milzma_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return (lib().milzma_last_error(self._h) or b"").decode()
+
+    # ---- unit-level batch API (device pointers as ints, e.g. torch_tensor.data_ptr()) --------
+    def decode_units(self, units, d_in, d_out, stream=0):
+        """units: ctypes array of Unit.  Returns (ctypes array of Result, kernel_ms, launches)."""
+        n = len(units)
+        results = (Result * n)()
+        r = lib().milzma_decode_units(self._h, units, n, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out),
+                                      results, ctypes.c_void_p(stream))
+        if r != OK:
+            raise InfraError("milzma_decode_units: " + self.last_error())
+        launches = ctypes.c_uint32()
+        ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
+        return results, ms, launches.value
+
+    def decode_units_host(self, units, h_in, out_bytes):
+        """Host-resident variant: h_in bytes-like; returns (results, bytearray output)."""
+        n = len(units)
+        results = (Result * n)()
+        pin, nin, keep = _as_buffer(h_in)
+        out = (ctypes.c_char * max(out_bytes, 1))()
+        r = lib().milzma_decode_units_host(self._h, units, n, pin, nin, ctypes.cast(out, ctypes.c_void_p),
+                                           out_bytes, results)
+        del keep
+        if r != OK:
+            raise InfraError("milzma_decode_units_host: " + self.last_error())
+        return results, bytearray(out)[:out_bytes]
+
+    # ---- whole-file API -------------------------------------------------------------------
+    def lzma(self, data, options=None):
+        out = _COutput()
+        p, n, keep = _as_buffer(data)
+        o = _c_options(options)
+        lib().milzma_lzma_decompress(self._h, p, n, ctypes.byref(o), ctypes.byref(out))
+        return Decoded(out)
+
+    def lzma2(self, data):
+        out = _COutput()
+        p, n, keep = _as_buffer(data)
+        lib().milzma_lzma2_decompress(self._h, p, n, ctypes.byref(out))
+        return Decoded(out)
+
+    def xz(self, data):
+        out = _COutput()
+        p, n, keep = _as_buffer(data)
+        lib().milzma_xz_decompress(self._h, p, n, ctypes.byref(out))
+        return Decoded(out)
+
+    def _batch(self, fn, datas, options=None, with_options=False):
+        n = len(datas)
+        bufs = [_as_buffer(d) for d in datas]
+        ptrs = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+        lens = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+        outs = (_COutput * n)()
+        if with_options:
+            o = _c_options(options)
+            fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
+        else:
+            fn(self._h, n, ptrs, lens, outs)
+        return [Decoded(outs[i]) for i in range(n)]
+
+    def lzma_batch(self, datas, options=None):
+        return self._batch(lib().milzma_lzma_decompress_batch, datas, options, True)
+
+    def lzma2_batch(self, datas):
+        return self._batch(lib().milzma_lzma2_decompress_batch, datas)
+
+    def xz_batch(self, datas):
+        return self._batch(lib().milzma_xz_decompress_batch, datas)
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MILZMA_USE_LOCAL_RANK") else 0)
+    return _default_ctx
+
+
+# ---- the crate's function surface -------------------------------------------------------------
+def _read_all(inp):
+    if isinstance(inp, (bytes, bytearray, memoryview)):
+        return bytes(inp), None, 0
+    start = inp.tell() if inp.seekable() else None
+    return inp.read(), inp, start
+
+
+def _deliver(dec, output, inp, start):
+    if isinstance(output, bytearray):
+        output += dec.data
+    else:
+        output.write(dec.data)
+    if inp is not None and start is not None:
+        inp.seek(start + dec.in_consumed)
+    err = dec.error()
+    if err is not None:
+        raise err
+
+
+def lzma_decompress_with_options(input, output, options, ctx=None):
+    data, inp, start = _read_all(input)
+    _deliver((ctx or default_context()).lzma(data, options), output, inp, start)
+
+
+def lzma_decompress(input, output, ctx=None):
+    lzma_decompress_with_options(input, output, Options(), ctx)
+
+
+def lzma2_decompress(input, output, ctx=None):
+    data, inp, start = _read_all(input)
+    _deliver((ctx or default_context()).lzma2(data), output, inp, start)
+
+
+def xz_decompress(input, output, ctx=None):
+    data, inp, start = _read_all(input)
+    _deliver((ctx or default_context()).xz(data), output, inp, start)
+
+
+# ---- host-only helpers (no GPU) ----------------------------------------------------------------
+def lzma_read_header(data, options=None):
+    """LzmaParams::read_header: returns (Unit, header_len) or raises the reference's error."""
+    u = Unit()
+    hl = ctypes.c_size_t()
+    out = _COutput()
+    p, n, keep = _as_buffer(data)
+    o = _c_options(options)
+    kind = lib().milzma_lzma_read_header(p, n, ctypes.byref(o), ctypes.byref(u), ctypes.byref(hl),
+                                         ctypes.byref(out))
+    if kind != OK:
+        raise _ERRORS[kind](out.msg.decode())
+    return u, hl.value
+
+
+def crc32(data):
+    p, n, keep = _as_buffer(data)
+    return lib().milzma_crc32(p, n)
+
+
+def crc64(data):
+    p, n, keep = _as_buffer(data)
+    return lib().milzma_crc64(p, n)
+
+
+def result_message(result, unit_kind):
+    buf = ctypes.create_string_buffer(400)
+    kind = lib().milzma_result_message(ctypes.byref(result), unit_kind, buf, 400)
+    return kind, buf.value.decode()

@@ -1,0 +1,1107 @@
+// host.cpp -- host side of the C ABI (include/milzma.h).
+//
+// What runs here is what the reference runs *around* its hot loop: header and container
+// parsing (LzmaParams::read_header, src/decode/lzma.rs:96-161; xz::decode_stream,
+// src/decode/xz.rs), option handling (src/decode/options.rs), error rendering (src/error.rs)
+// and -- new -- turning many streams / blocks into one batch of wavefront-sized decode units.
+// All decoding happens in the HIP kernels; there is no CPU decode path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+#include "milzma.h"
+
+using namespace milzma;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct milzma_ctx {
+  int device = 0;
+  std::string err;
+  DevBuf units, order, results, scratch, in, out;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  uint32_t last_launches = 0;
+};
+
+namespace {
+
+bool hip_ok(milzma_ctx* ctx, hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return false;
+}
+
+bool dev_reserve(milzma_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return true;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = std::max(bytes, size_t(1) << 16);
+  want = (want + 4095) & ~size_t(4095);
+  if (!hip_ok(ctx, hipMalloc(&b.p, want), "hipMalloc")) return false;
+  b.cap = want;
+  return true;
+}
+
+void dev_release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+}  // namespace
+
+extern "C" uint32_t milzma_abi_version(void) { return MILZMA_ABI_VERSION; }
+
+extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
+  if (!out_ctx) return MILZMA_INFRA_ERROR;
+  *out_ctx = nullptr;
+  int count = 0;
+  if (!hip_ok(nullptr, hipGetDeviceCount(&count), "hipGetDeviceCount")) return MILZMA_INFRA_ERROR;
+  if (count <= 0 || device < 0 || device >= count) {
+    g_create_error = "no usable HIP device (this library has no CPU decode path)";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (!hip_ok(nullptr, hipSetDevice(device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
+  hipDeviceProp_t prop;
+  if (!hip_ok(nullptr, hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return MILZMA_INFRA_ERROR;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only";
+    return MILZMA_INFRA_ERROR;
+  }
+  auto* ctx = new milzma_ctx();
+  ctx->device = device;
+  if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
+      !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
+    delete ctx;
+    return MILZMA_INFRA_ERROR;
+  }
+  *out_ctx = ctx;
+  return MILZMA_OK;
+}
+
+extern "C" void milzma_destroy(milzma_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  dev_release(ctx->units);
+  dev_release(ctx->order);
+  dev_release(ctx->results);
+  dev_release(ctx->scratch);
+  dev_release(ctx->in);
+  dev_release(ctx->out);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+}
+
+extern "C" const char* milzma_last_error(const milzma_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" float milzma_last_kernel_ms(const milzma_ctx* ctx, uint32_t* launches) {
+  if (launches) *launches = ctx ? ctx->last_launches : 0;
+  return ctx ? ctx->last_ms : 0.f;
+}
+
+extern "C" void milzma_free(void* p) { free(p); }
+
+extern "C" void milzma_default_options(milzma_options* opt) {
+  if (opt) memset(opt, 0, sizeof *opt);
+}
+
+// ------------------------------------------------------------------------------------------
+// the batch entry point
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+constexpr uint32_t kSpillBatch = 32;  // blocks per launch of the HBM-spill class (6 MiB scratch each)
+
+LitClass classify(const milzma_unit& u) {
+  if (u.kind != MILZMA_KIND_RAW_LZMA) return kLitLds3;  // LZMA2 starts small, NEED_LCLP promotes it
+  const uint32_t lclp = uint32_t(u.lc) + u.lp;
+  if (lclp <= 3) return kLitLds3;
+  if (lclp <= 4) return kLitLds4;
+  return kLitSpill;
+}
+
+// Launches `order` (unit indices) in class `cls`; kernel time is accumulated into ctx.
+bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& order, uint32_t order_base,
+                  const uint8_t* d_in, uint8_t* d_out, hipStream_t stream) {
+  if (order.empty()) return true;
+  auto* d_units = static_cast<const milzma_unit*>(ctx->units.p);
+  auto* d_order = static_cast<const uint32_t*>(ctx->order.p) + order_base;
+  auto* d_results = static_cast<milzma_result*>(ctx->results.p);
+  const uint32_t n = uint32_t(order.size());
+  const uint32_t step = cls == kLitSpill ? kSpillBatch : n;
+  if (cls == kLitSpill && !dev_reserve(ctx, ctx->scratch, kSpillBytesPerBlock * std::min(n, kSpillBatch))) return false;
+  for (uint32_t i = 0; i < n; i += step) {
+    const uint32_t m = std::min(step, n - i);
+    if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
+    if (!hip_ok(ctx,
+                launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
+                               static_cast<uint16_t*>(ctx->scratch.p), stream),
+                "kernel launch"))
+      return false;
+    if (!hip_ok(ctx, hipEventRecord(ctx->ev1, stream), "hipEventRecord")) return false;
+    if (!hip_ok(ctx, hipEventSynchronize(ctx->ev1), "hipEventSynchronize")) return false;
+    float ms = 0.f;
+    if (!hip_ok(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime")) return false;
+    ctx->last_ms += ms;
+    ctx->last_launches++;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
+                                   void* d_out, milzma_result* results, void* hip_stream) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  ctx->last_ms = 0.f;
+  ctx->last_launches = 0;
+  if (n == 0) return MILZMA_OK;
+  if (!units || !results) {
+    ctx->err = "null units/results";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+  // Partition by launch class; inside a class longest input first, so that the hardware's
+  // in-order block dispatch behaves like longest-processing-time-first scheduling.
+  std::vector<uint32_t> order[kNumLitClasses];
+  for (uint32_t i = 0; i < n; i++) order[classify(units[i])].push_back(i);
+  std::vector<uint32_t> flat;
+  flat.reserve(n);
+  uint32_t base[kNumLitClasses];
+  for (int c = 0; c < kNumLitClasses; c++) {
+    std::stable_sort(order[c].begin(), order[c].end(),
+                     [&](uint32_t a, uint32_t b) { return units[a].in_len > units[b].in_len; });
+    base[c] = uint32_t(flat.size());
+    flat.insert(flat.end(), order[c].begin(), order[c].end());
+  }
+
+  if (!dev_reserve(ctx, ctx->units, size_t(n) * sizeof(milzma_unit)) ||
+      !dev_reserve(ctx, ctx->order, size_t(n) * 2 * sizeof(uint32_t)) ||
+      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)))
+    return MILZMA_INFRA_ERROR;
+  if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
+              "H2D units") ||
+      !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, flat.data(), size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, stream),
+              "H2D order"))
+    return MILZMA_INFRA_ERROR;
+
+  for (int c = 0; c < kNumLitClasses; c++)
+    if (!launch_class(ctx, LitClass(c), order[c], base[c], static_cast<const uint8_t*>(d_in),
+                      static_cast<uint8_t*>(d_out), stream))
+      return MILZMA_INFRA_ERROR;
+
+  if (!hip_ok(ctx, hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
+              "D2H results") ||
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+    return MILZMA_INFRA_ERROR;
+
+  // LZMA2 units that met props with lc+lp == 4 mid-stream: run them again in the bigger class.
+  std::vector<uint32_t> again;
+  for (uint32_t i = 0; i < n; i++)
+    if (results[i].status == MILZMA_ST_NEED_LCLP && results[i].err_a <= 4 && classify(units[i]) == kLitLds3)
+      again.push_back(i);
+  if (!again.empty()) {
+    if (!hip_ok(ctx,
+                hipMemcpyAsync(static_cast<uint32_t*>(ctx->order.p) + n, again.data(), again.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, stream),
+                "H2D order"))
+      return MILZMA_INFRA_ERROR;
+    if (!launch_class(ctx, kLitLds4, again, n, static_cast<const uint8_t*>(d_in), static_cast<uint8_t*>(d_out), stream))
+      return MILZMA_INFRA_ERROR;
+    if (!hip_ok(ctx,
+                hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
+                "D2H results") ||
+        !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+      return MILZMA_INFRA_ERROR;
+  }
+  return MILZMA_OK;
+}
+
+extern "C" int milzma_decode_units_host(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
+                                        size_t in_bytes, void* h_out, size_t out_bytes, milzma_result* results) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
+  if (!dev_reserve(ctx, ctx->in, in_bytes + 512) || !dev_reserve(ctx, ctx->out, out_bytes + 512)) return MILZMA_INFRA_ERROR;
+  if (in_bytes && !hip_ok(ctx, hipMemcpy(ctx->in.p, h_in, in_bytes, hipMemcpyHostToDevice), "H2D input"))
+    return MILZMA_INFRA_ERROR;
+  const int r = milzma_decode_units(ctx, units, n, ctx->in.p, ctx->out.p, results, nullptr);
+  if (r != MILZMA_OK) return r;
+  if (out_bytes && !hip_ok(ctx, hipMemcpy(h_out, ctx->out.p, out_bytes, hipMemcpyDeviceToHost), "D2H output"))
+    return MILZMA_INFRA_ERROR;
+  return MILZMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// error rendering: src/error.rs:28-36 prefixes + the message of each hot-path error site
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+const char* const kEofMsg = "failed to fill whole buffer";  // io::ErrorKind::UnexpectedEof
+const char* const kPrefix[] = {"", "io error: ", "header too short: ", "lzma error: ", "xz error: ", "milzma: "};
+
+int render(char* msg, size_t cap, int kind, const char* fmt, ...) {
+  if (msg && cap) {
+    const int n = snprintf(msg, cap, "%s", kPrefix[kind]);
+    va_list ap;
+    va_start(ap, fmt);
+    if (n >= 0 && size_t(n) < cap) vsnprintf(msg + n, cap - size_t(n), fmt, ap);
+    va_end(ap);
+  }
+  return kind;
+}
+
+}  // namespace
+
+extern "C" int milzma_result_message(const milzma_result* r, uint32_t unit_kind, char* msg, size_t cap) {
+  const unsigned long long a = r->err_a, b = r->err_b;
+  switch (r->status) {
+    case MILZMA_ST_OK:
+      if (msg && cap) msg[0] = 0;
+      return MILZMA_OK;
+    case MILZMA_ST_RC_INIT:
+      return render(msg, cap, MILZMA_LZMA_ERROR,
+                    unit_kind == MILZMA_KIND_LZMA2 ? "LZMA input too short: %s" : "LZMA stream too short: %s", kEofMsg);
+    case MILZMA_ST_INPUT_EOF: return render(msg, cap, MILZMA_IO_ERROR, "%s", kEofMsg);
+    case MILZMA_ST_MATCH_DIST_DICT:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "Match distance %llu is beyond dictionary size %llu", a, b);
+    case MILZMA_ST_MATCH_DIST_OUT:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "Match distance %llu is beyond output size %llu", a, b);
+    case MILZMA_ST_LZ_DIST_DICT:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZ distance %llu is beyond dictionary size %llu", a, b);
+    case MILZMA_ST_LZ_DIST_OUT:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZ distance %llu is beyond output size %llu", a, b);
+    case MILZMA_ST_MEMLIMIT: return render(msg, cap, MILZMA_LZMA_ERROR, "exceeded memory limit of %llu", a);
+    case MILZMA_ST_MARKER_TRAILING:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "Found end-of-stream marker but more bytes are available");
+    case MILZMA_ST_SIZE_MISMATCH:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "Expected unpacked size of %llu but decompressed to %llu", a, b);
+    case MILZMA_ST_L2_STATUS_EOF: return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 expected new status: %s", kEofMsg);
+    case MILZMA_ST_L2_INVALID_STATUS:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 invalid status %llu, must be 0, 1, 2 or >= 128", a);
+    case MILZMA_ST_L2_UNPACKED_EOF:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 expected unpacked size: %s", kEofMsg);
+    case MILZMA_ST_L2_PACKED_EOF: return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 expected packed size: %s", kEofMsg);
+    case MILZMA_ST_L2_PROPS_EOF:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 expected new properties: %s", kEofMsg);
+    case MILZMA_ST_L2_PROPS_INVALID:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 invalid properties: %llu must be < 225", a);
+    case MILZMA_ST_L2_LCLP:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 invalid properties: lc + lp (%llu + %llu) must be <= 4", a, b);
+    case MILZMA_ST_L2_STORED_EOF:
+      return render(msg, cap, MILZMA_LZMA_ERROR, "LZMA2 expected %llu uncompressed bytes: %s", a, kEofMsg);
+    case MILZMA_ST_OUT_FULL: return render(msg, cap, MILZMA_INFRA_ERROR, "output slice too small");
+    case MILZMA_ST_NEED_LCLP: return render(msg, cap, MILZMA_INFRA_ERROR, "literal table class too small for lc+lp=%llu", a);
+    case MILZMA_ST_BAD_UNIT: return render(msg, cap, MILZMA_INFRA_ERROR, "bad unit descriptor");
+    default: return render(msg, cap, MILZMA_INFRA_ERROR, "unknown status %u", r->status);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CRC-32 (ISO-HDLC) / CRC-64 (XZ), slicing-by-8 (src/xz/crc.rs:1-4 names the polynomials)
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct CrcTables {
+  uint32_t t32[8][256];
+  uint64_t t64[8][256];
+  CrcTables() {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      uint64_t d = i;
+      for (int j = 0; j < 8; j++) {
+        c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        d = (d & 1) ? (d >> 1) ^ 0xC96C5795D7870F42ull : d >> 1;
+      }
+      t32[0][i] = c;
+      t64[0][i] = d;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+      for (int k = 1; k < 8; k++) {
+        t32[k][i] = (t32[k - 1][i] >> 8) ^ t32[0][t32[k - 1][i] & 0xFF];
+        t64[k][i] = (t64[k - 1][i] >> 8) ^ t64[0][t64[k - 1][i] & 0xFF];
+      }
+  }
+};
+const CrcTables& crc_tables() {
+  static const CrcTables t;
+  return t;
+}
+
+uint32_t crc32_update(uint32_t c, const uint8_t* p, size_t n) {
+  const auto& T = crc_tables().t32;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^ T[3][hi & 0xFF] ^
+        T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c;
+}
+
+}  // namespace
+
+extern "C" uint32_t milzma_crc32(const uint8_t* p, size_t n) { return ~crc32_update(0xFFFFFFFFu, p, n); }
+
+extern "C" uint64_t milzma_crc64(const uint8_t* p, size_t n) {
+  const auto& T = crc_tables().t64;
+  uint64_t c = ~uint64_t(0);
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = T[7][w & 0xFF] ^ T[6][(w >> 8) & 0xFF] ^ T[5][(w >> 16) & 0xFF] ^ T[4][(w >> 24) & 0xFF] ^
+        T[3][(w >> 32) & 0xFF] ^ T[2][(w >> 40) & 0xFF] ^ T[1][(w >> 48) & 0xFF] ^ T[0][w >> 56];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers shared by the whole-file entry points
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+struct Cursor {  // io::BufRead over a slice
+  const uint8_t* p;
+  size_t pos, end;
+  bool u8(uint8_t* v) {
+    if (pos >= end) return false;
+    *v = p[pos++];
+    return true;
+  }
+  bool exact(uint8_t* dst, size_t n) {  // read_exact: a short read consumes what there is
+    if (end - pos < n) {
+      pos = end;
+      return false;
+    }
+    if (dst) memcpy(dst, p + pos, n);
+    pos += n;
+    return true;
+  }
+  bool u16be(uint32_t* v) {
+    uint8_t b[2];
+    if (!exact(b, 2)) return false;
+    *v = (uint32_t(b[0]) << 8) | b[1];
+    return true;
+  }
+  bool u32le(uint32_t* v) {
+    uint8_t b[4];
+    if (!exact(b, 4)) return false;
+    *v = uint32_t(b[0]) | (uint32_t(b[1]) << 8) | (uint32_t(b[2]) << 16) | (uint32_t(b[3]) << 24);
+    return true;
+  }
+  bool u64le(uint64_t* v) {
+    uint8_t b[8];
+    if (!exact(b, 8)) return false;
+    *v = 0;
+    for (int i = 7; i >= 0; i--) *v = (*v << 8) | b[i];
+    return true;
+  }
+  bool eof() const { return pos >= end; }
+};
+
+void out_reset(milzma_output* o) {
+  o->data = nullptr;
+  o->len = 0;
+  o->in_consumed = 0;
+  o->kind = MILZMA_OK;
+  o->msg[0] = 0;
+}
+
+int out_fail(milzma_output* o, int kind, const char* fmt, ...) {
+  o->kind = kind;
+  const int n = snprintf(o->msg, sizeof o->msg, "%s", kPrefix[kind]);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(o->msg + n, sizeof o->msg - size_t(n), fmt, ap);
+  va_end(ap);
+  return kind;
+}
+
+int out_io_eof(milzma_output* o) { return out_fail(o, MILZMA_IO_ERROR, "%s", kEofMsg); }
+
+bool out_set_data(milzma_output* o, const uint8_t* p, size_t n) {
+  o->data = static_cast<uint8_t*>(malloc(n ? n : 1));
+  if (!o->data) return false;
+  if (n) memcpy(o->data, p, n);
+  o->len = n;
+  return true;
+}
+
+int infra(milzma_ctx* ctx, milzma_output* o) {
+  return out_fail(o, MILZMA_INFRA_ERROR, "%s", ctx ? ctx->err.c_str() : "no context");
+}
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// One unit through the device with host buffers, growing the output slice while the kernel
+// reports OUT_FULL.  `cap_hint` is the first slice size to try.
+struct SingleDecode {
+  milzma_result res;
+  std::vector<uint8_t> out;  // the unit's output slice (res.out_len bytes valid, capped by size)
+};
+
+bool decode_single(milzma_ctx* ctx, milzma_unit u, const uint8_t* in, size_t in_len, size_t cap_hint, SingleDecode* sd) {
+  size_t cap = std::max<size_t>(cap_hint, 4096);
+  for (;;) {
+    cap = std::min<size_t>(round_up(cap, 256), MILZMA_MAX_UNIT_BYTES);
+    u.in_off = 0;
+    u.in_len = in_len;
+    u.out_off = 0;
+    u.out_cap = cap;
+    sd->out.resize(cap);
+    if (milzma_decode_units_host(ctx, &u, 1, in, in_len, sd->out.data(), cap, &sd->res) != MILZMA_OK) return false;
+    if (sd->res.status != MILZMA_ST_OUT_FULL || cap >= MILZMA_MAX_UNIT_BYTES) return true;
+    cap = cap * 4;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// .lzma: LzmaParams::read_header (src/decode/lzma.rs:96-161)
+// ------------------------------------------------------------------------------------------
+
+extern "C" int milzma_lzma_read_header(const uint8_t* in, size_t in_len, const milzma_options* opt, milzma_unit* unit,
+                                       size_t* header_len, milzma_output* out) {
+  milzma_options dflt;
+  milzma_default_options(&dflt);
+  if (!opt) opt = &dflt;
+  milzma_output scratch;
+  if (!out) out = &scratch;
+  out_reset(out);
+  Cursor c{in, 0, in_len};
+  uint8_t props;
+  if (!c.u8(&props)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+  uint32_t pb = props;
+  if (pb >= 225) return out_fail(out, MILZMA_LZMA_ERROR, "LZMA header invalid properties: %u must be < 225", pb);
+  const uint32_t lc = pb % 9;
+  pb /= 9;
+  const uint32_t lp = pb % 5;
+  pb /= 5;
+  uint32_t dict;
+  if (!c.u32le(&dict)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+  if (dict < 0x1000) dict = 0x1000;
+  uint64_t unpacked = MILZMA_SIZE_UNKNOWN;
+  switch (opt->unpacked_size_mode) {
+    case MILZMA_READ_FROM_HEADER: {
+      uint64_t v;
+      if (!c.u64le(&v)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+      unpacked = v;  // 0xFFFF_FFFF_FFFF_FFFF == marker mode == MILZMA_SIZE_UNKNOWN
+      break;
+    }
+    case MILZMA_READ_HEADER_BUT_USE_PROVIDED: {
+      uint64_t v;
+      if (!c.u64le(&v)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+      unpacked = opt->provided_is_some ? opt->provided : MILZMA_SIZE_UNKNOWN;
+      break;
+    }
+    default: unpacked = opt->provided_is_some ? opt->provided : MILZMA_SIZE_UNKNOWN; break;
+  }
+  memset(unit, 0, sizeof *unit);
+  unit->kind = MILZMA_KIND_RAW_LZMA;
+  unit->lc = uint8_t(lc);
+  unit->lp = uint8_t(lp);
+  unit->pb = uint8_t(pb);
+  unit->dict_size = dict;
+  unit->unpacked_size = unpacked;
+  unit->memlimit = opt->memlimit_is_some ? opt->memlimit : MILZMA_NO_LIMIT;
+  if (header_len) *header_len = c.pos;
+  return MILZMA_OK;
+}
+
+namespace {
+
+// slice size to try first for a RAW unit
+size_t lzma_cap_hint(const milzma_unit& u, size_t payload_len) {
+  if (u.unpacked_size != MILZMA_SIZE_UNKNOWN)
+    return size_t(std::min<uint64_t>(u.unpacked_size, MILZMA_MAX_UNIT_BYTES - 512)) + 288;  // + one overshooting match
+  return std::max<size_t>(1 << 16, payload_len * 6);
+}
+
+// Turns a finished RAW/LZMA2 unit into what the caller's writer / reader saw.
+int finish_stream(const milzma_result& r, uint32_t kind, const uint8_t* slice, size_t slice_len, size_t header_len,
+                  milzma_output* out) {
+  out->in_consumed = header_len + size_t(r.in_consumed);
+  const size_t visible = size_t(std::min<uint64_t>(r.out_flushed, slice_len));
+  if (!out_set_data(out, slice, visible)) return out_fail(out, MILZMA_INFRA_ERROR, "out of memory");
+  out->kind = milzma_result_message(&r, kind, out->msg, sizeof out->msg);
+  return out->kind;
+}
+
+}  // namespace
+
+extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const milzma_options* opt,
+                                      milzma_output* out) {
+  milzma_unit u;
+  size_t hl = 0;
+  const int hr = milzma_lzma_read_header(in, in_len, opt, &u, &hl, out);
+  if (hr != MILZMA_OK) return hr;
+  SingleDecode sd;
+  if (!decode_single(ctx, u, in + hl, in_len - hl, lzma_cap_hint(u, in_len - hl), &sd)) return infra(ctx, out);
+  return finish_stream(sd.res, MILZMA_KIND_RAW_LZMA, sd.out.data(), sd.out.size(), hl, out);
+}
+
+extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
+  out_reset(out);
+  milzma_unit u;
+  memset(&u, 0, sizeof u);
+  u.kind = MILZMA_KIND_LZMA2;
+  SingleDecode sd;
+  if (!decode_single(ctx, u, in, in_len, std::max<size_t>(1 << 16, in_len * 6), &sd)) return infra(ctx, out);
+  return finish_stream(sd.res, MILZMA_KIND_LZMA2, sd.out.data(), sd.out.size(), 0, out);
+}
+
+// Batch driver for RAW / LZMA2 streams: one launch for all, stragglers (OUT_FULL) one by one.
+namespace {
+
+int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, const milzma_options* opt,
+                 bool lzma2, milzma_output* outs) {
+  std::vector<milzma_unit> units;
+  std::vector<uint32_t> owner;  // unit -> stream
+  std::vector<size_t> hdr(n, 0);
+  size_t in_total = 0, out_total = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    out_reset(&outs[i]);
+    milzma_unit u;
+    if (lzma2) {
+      memset(&u, 0, sizeof u);
+      u.kind = MILZMA_KIND_LZMA2;
+    } else if (milzma_lzma_read_header(ins[i], in_lens[i], opt, &u, &hdr[i], &outs[i]) != MILZMA_OK) {
+      continue;
+    }
+    const size_t payload = in_lens[i] - hdr[i];
+    if (payload > MILZMA_MAX_UNIT_BYTES) {
+      out_fail(&outs[i], MILZMA_INFRA_ERROR, "stream larger than MILZMA_MAX_UNIT_BYTES");
+      continue;
+    }
+    u.in_off = in_total;
+    u.in_len = payload;
+    u.out_off = out_total;
+    u.out_cap = std::min<size_t>(round_up(lzma2 ? std::max<size_t>(1 << 16, payload * 6) : lzma_cap_hint(u, payload), 256),
+                                 MILZMA_MAX_UNIT_BYTES);
+    in_total += round_up(payload, 256);
+    out_total += u.out_cap;
+    units.push_back(u);
+    owner.push_back(i);
+  }
+  if (units.empty()) return MILZMA_OK;
+  std::vector<uint8_t> hin(in_total), hout(out_total);
+  for (size_t k = 0; k < units.size(); k++)
+    memcpy(hin.data() + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+  std::vector<milzma_result> res(units.size());
+  if (milzma_decode_units_host(ctx, units.data(), uint32_t(units.size()), hin.data(), in_total, hout.data(), out_total,
+                               res.data()) != MILZMA_OK) {
+    for (uint32_t i : owner) infra(ctx, &outs[i]);
+    return MILZMA_INFRA_ERROR;
+  }
+  const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
+  for (size_t k = 0; k < units.size(); k++) {
+    const uint32_t i = owner[k];
+    if (res[k].status == MILZMA_ST_OUT_FULL) {  // guessed slice too small: redo alone with growth
+      SingleDecode sd;
+      if (!decode_single(ctx, units[k], ins[i] + hdr[i], size_t(units[k].in_len), size_t(units[k].out_cap) * 4, &sd)) {
+        infra(ctx, &outs[i]);
+        continue;
+      }
+      finish_stream(sd.res, kind, sd.out.data(), sd.out.size(), hdr[i], &outs[i]);
+    } else {
+      finish_stream(res[k], kind, hout.data() + units[k].out_off, size_t(units[k].out_cap), hdr[i], &outs[i]);
+    }
+  }
+  return MILZMA_OK;
+}
+
+}  // namespace
+
+extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                            const milzma_options* opt, milzma_output* outs) {
+  return stream_batch(ctx, n, ins, in_lens, opt, false, outs);
+}
+
+extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                             milzma_output* outs) {
+  return stream_batch(ctx, n, ins, in_lens, nullptr, true, outs);
+}
+
+// ------------------------------------------------------------------------------------------
+// .xz: xz::decode_stream (src/decode/xz.rs:18-94) with the LZMA2 payload of each block decoded
+// on the device.  The walk below is the reference's, statement for statement; what is new is
+// that block payloads can be decoded ahead of the walk, all at once (see xz_batch).
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+enum { CHECK_NONE = 0x00, CHECK_CRC32 = 0x01, CHECK_CRC64 = 0x04, CHECK_SHA256 = 0x0A };
+
+const char* check_name(int m) {
+  switch (m) {
+    case CHECK_NONE: return "None";
+    case CHECK_CRC32: return "Crc32";
+    case CHECK_CRC64: return "Crc64";
+    default: return "Sha256";
+  }
+}
+
+// StreamFlags::parse (src/xz/mod.rs:15-31) + CheckMethod::try_from (:54-66)
+int stream_flags_parse(uint32_t field, int* check, milzma_output* o) {
+  const uint32_t b0 = (field >> 8) & 0xFF, b1 = field & 0xFF;
+  if (b0 != 0) return out_fail(o, MILZMA_XZ_ERROR, "Invalid null byte in Stream Flags: %x", b0);
+  if (b1 != CHECK_NONE && b1 != CHECK_CRC32 && b1 != CHECK_CRC64 && b1 != CHECK_SHA256)
+    return out_fail(o, MILZMA_XZ_ERROR, "Invalid check method %x, expected one of [0x00, 0x01, 0x04, 0x0A]", b1);
+  *check = int(b1);
+  return MILZMA_OK;
+}
+
+// get_multibyte (src/decode/xz.rs:448-464): 0 ok, 1 eof, 2 invalid
+int get_multibyte(Cursor& c, uint64_t* out) {
+  uint64_t r = 0;
+  for (int i = 0; i < 9; i++) {
+    uint8_t b;
+    if (!c.u8(&b)) return 1;
+    r ^= uint64_t(b & 0x7F) << (i * 7);
+    if ((b & 0x80) == 0) {
+      *out = r;
+      return 0;
+    }
+  }
+  return 2;
+}
+int multibyte_err(int rc, milzma_output* o) {
+  return rc == 1 ? out_io_eof(o) : out_fail(o, MILZMA_XZ_ERROR, "Invalid multi-byte encoding");
+}
+
+struct BlockHeader {
+  size_t num_filters = 0;
+  size_t props_len[4] = {0, 0, 0, 0};
+  bool has_packed = false, has_unpacked = false;
+  uint64_t packed = 0, unpacked = 0;
+};
+
+// read_block_header (src/decode/xz.rs:356-446); `c` is limited to the header bytes
+int read_block_header(Cursor& c, uint64_t header_size, BlockHeader* bh, milzma_output* o) {
+  uint8_t flags;
+  if (!c.u8(&flags)) return out_io_eof(o);
+  const size_t num_filters = size_t(flags & 3) + 1;
+  if (flags & 0x3C)
+    return out_fail(o, MILZMA_XZ_ERROR, "Invalid block flags %u, reserved bits (mask 0x3C) must be zero", unsigned(flags));
+  bh->has_packed = (flags & 0x40) != 0;
+  bh->has_unpacked = (flags & 0x80) != 0;
+  int rc;
+  if (bh->has_packed && (rc = get_multibyte(c, &bh->packed))) return multibyte_err(rc, o);
+  if (bh->has_unpacked && (rc = get_multibyte(c, &bh->unpacked))) return multibyte_err(rc, o);
+  for (size_t i = 0; i < num_filters; i++) {
+    uint64_t id, psize;
+    if ((rc = get_multibyte(c, &id))) return multibyte_err(rc, o);
+    if (id != 0x21) return out_fail(o, MILZMA_XZ_ERROR, "Unknown filter id %" PRIu64, id);
+    if ((rc = get_multibyte(c, &psize))) return multibyte_err(rc, o);
+    if (psize > header_size)
+      return out_fail(o, MILZMA_XZ_ERROR, "Size of filter properties exceeds block header size (%" PRIu64 " > %" PRIu64 ")",
+                      psize, header_size);
+    if (!c.exact(nullptr, size_t(psize)))
+      return out_fail(o, MILZMA_XZ_ERROR, "Could not read filter properties of size %" PRIu64 ": %s", psize, kEofMsg);
+    bh->props_len[bh->num_filters++] = size_t(psize);
+  }
+  while (c.pos < c.end) {  // util::flush_zero_padding (src/decode/util.rs:14-36)
+    if (c.p[c.pos] != 0) return out_fail(o, MILZMA_XZ_ERROR, "Invalid block header padding, must be null bytes");
+    c.pos++;
+  }
+  return MILZMA_OK;
+}
+
+// Result of decoding one LZMA2 payload (Lzma2Decoder::new().decompress, src/decode/xz.rs:350).
+struct Payload {
+  milzma_result res;
+  const uint8_t* data = nullptr;  // res.out_len bytes (valid when res.status == OK)
+  std::vector<uint8_t> own;       // backing store when decoded on demand
+};
+// Decodes the LZMA2 stream that starts at in[0]; the reader's EOF is in_len.
+using PayloadFn = std::function<bool(const uint8_t* in, size_t in_len, size_t cap_hint, Payload*)>;
+
+struct Record {
+  uint64_t unpadded, unpacked;
+};
+
+// read_block (src/decode/xz.rs:196-290); block_start = position of the header-size byte
+int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, std::vector<uint8_t>& output, int check,
+               std::vector<Record>& records, uint8_t hsize_byte, const PayloadFn& decode, milzma_output* o) {
+  const uint64_t header_size = (uint64_t(hsize_byte) << 2) - 1;
+  BlockHeader bh;
+  const size_t hdr_begin = c.pos, saved_end = c.end;
+  const size_t hdr_end = uint64_t(c.end - c.pos) > header_size ? c.pos + size_t(header_size) : c.end;
+  c.end = hdr_end;  // count_input.take(header_size) behind a BufReader + CrcDigestRead
+  const int hr = read_block_header(c, header_size, &bh, o);
+  c.end = saved_end;
+  if (hr) return hr;
+  c.pos = hdr_end;
+  uint32_t digest = crc32_update(0xFFFFFFFFu, &hsize_byte, 1);
+  digest = ~crc32_update(digest, c.p + hdr_begin, hdr_end - hdr_begin);
+  uint32_t crc;
+  if (!c.u32le(&crc)) return out_io_eof(o);
+  if (crc != digest)
+    return out_fail(o, MILZMA_XZ_ERROR, "Invalid header CRC32: expected 0x%08x but got 0x%08x", crc, digest);
+
+  Payload cur;
+  for (size_t i = 0; i < bh.num_filters; i++) {
+    // decode_filter (src/decode/xz.rs:335-354)
+    if (bh.props_len[i] != 1) return out_fail(o, MILZMA_XZ_ERROR, "Invalid properties for filter Lzma2");
+    Payload next;
+    const uint8_t* src = i == 0 ? c.p + c.pos : cur.data;
+    const size_t src_len = i == 0 ? c.end - c.pos : size_t(cur.res.out_len);
+    const size_t hint = (i == 0 && bh.has_unpacked) ? size_t(std::min<uint64_t>(bh.unpacked, MILZMA_MAX_UNIT_BYTES)) : 0;
+    if (!decode(src, src_len, hint, &next)) return infra(ctx, o);
+    if (next.res.status != MILZMA_ST_OK) {
+      o->kind = milzma_result_message(&next.res, MILZMA_KIND_LZMA2, o->msg, sizeof o->msg);
+      return o->kind;
+    }
+    if (i == 0) {
+      const uint64_t packed = next.res.in_consumed;
+      c.pos += size_t(packed);
+      if (bh.has_packed && packed != bh.packed)
+        return out_fail(o, MILZMA_XZ_ERROR, "Invalid compressed size: expected %" PRIu64 " but got %" PRIu64, bh.packed,
+                        packed);
+    }
+    cur = std::move(next);
+    if (!cur.own.empty()) cur.data = cur.own.data();
+  }
+  const uint64_t unpacked_size = cur.res.out_len;
+  if (bh.has_unpacked && unpacked_size != bh.unpacked)
+    return out_fail(o, MILZMA_XZ_ERROR, "Invalid decompressed size: expected %" PRIu64 " but got %" PRIu64, bh.unpacked,
+                    unpacked_size);
+  const size_t count = c.pos - block_start;
+  const size_t padding = ((count ^ 3) + 1) & 3;
+  for (size_t i = 0; i < padding; i++) {
+    uint8_t b;
+    if (!c.u8(&b)) return out_io_eof(o);
+    if (b != 0) return out_fail(o, MILZMA_XZ_ERROR, "Invalid block padding, must be null bytes");
+  }
+  // validate_block_check (src/decode/xz.rs:292-333)
+  switch (check) {
+    case CHECK_NONE: break;
+    case CHECK_CRC32: {
+      uint32_t want;
+      if (!c.u32le(&want)) return out_io_eof(o);
+      const uint32_t got = milzma_crc32(cur.data, size_t(unpacked_size));
+      if (want != got) return out_fail(o, MILZMA_XZ_ERROR, "Invalid block CRC32, expected 0x%08x but got 0x%08x", want, got);
+      break;
+    }
+    case CHECK_CRC64: {
+      uint64_t want;
+      if (!c.u64le(&want)) return out_io_eof(o);
+      const uint64_t got = milzma_crc64(cur.data, size_t(unpacked_size));
+      if (want != got)
+        return out_fail(o, MILZMA_XZ_ERROR, "Invalid block CRC64, expected 0x%016" PRIx64 " but got 0x%016" PRIx64, want, got);
+      break;
+    }
+    default: return out_fail(o, MILZMA_XZ_ERROR, "Unsupported SHA-256 checksum (not yet implemented)");
+  }
+  output.insert(output.end(), cur.data, cur.data + size_t(unpacked_size));
+  records.push_back(Record{uint64_t(c.pos - block_start - padding), unpacked_size});
+  return MILZMA_OK;
+}
+
+// check_index (src/decode/xz.rs:96-171); index_start = position of the 0x00 indicator byte
+int check_index(Cursor& c, size_t index_start, const std::vector<Record>& records, milzma_output* o) {
+  const size_t digest_from = c.pos;
+  uint64_t num, v;
+  int rc;
+  if ((rc = get_multibyte(c, &num))) return multibyte_err(rc, o);
+  if (num != records.size())
+    return out_fail(o, MILZMA_XZ_ERROR, "Expected %" PRIu64 " records but got %zu records", num, records.size());
+  for (size_t i = 0; i < records.size(); i++) {
+    if ((rc = get_multibyte(c, &v))) return multibyte_err(rc, o);
+    if (v != records[i].unpadded)
+      return out_fail(o, MILZMA_XZ_ERROR,
+                      "Invalid index for record %zu: unpadded size (%" PRIu64 ") does not match index (%" PRIu64 ")", i,
+                      records[i].unpadded, v);
+    if ((rc = get_multibyte(c, &v))) return multibyte_err(rc, o);
+    if (v != records[i].unpacked)
+      return out_fail(o, MILZMA_XZ_ERROR,
+                      "Invalid index for record %zu: unpacked size (%" PRIu64 ") does not match index (%" PRIu64 ")", i,
+                      records[i].unpacked, v);
+  }
+  const size_t count = c.pos - index_start;
+  const size_t padding = ((count ^ 3) + 1) & 3;
+  for (size_t i = 0; i < padding; i++) {
+    uint8_t b;
+    if (!c.u8(&b)) return out_io_eof(o);
+    if (b != 0) return out_fail(o, MILZMA_XZ_ERROR, "Invalid index padding, must be null bytes");
+  }
+  const uint8_t tag = 0;
+  uint32_t digest = crc32_update(0xFFFFFFFFu, &tag, 1);
+  digest = ~crc32_update(digest, c.p + digest_from, c.pos - digest_from);
+  uint32_t crc;
+  if (!c.u32le(&crc)) return out_io_eof(o);
+  if (crc != digest) return out_fail(o, MILZMA_XZ_ERROR, "Invalid index CRC32: expected 0x%08x but got 0x%08x", crc, digest);
+  return MILZMA_OK;
+}
+
+// xz::decode_stream (src/decode/xz.rs:18-94) + StreamHeader::parse (src/xz/header.rs:20-51)
+int xz_walk(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const PayloadFn& decode, milzma_output* o) {
+  static const uint8_t kMagic[6] = {0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00};
+  out_reset(o);
+  Cursor c{in, 0, in_len};
+  std::vector<uint8_t> output;
+  std::vector<Record> records;
+  int r = MILZMA_OK;
+  auto done = [&](int rr) {
+    o->in_consumed = c.pos;
+    if (!out_set_data(o, output.data(), output.size())) return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
+    return rr;
+  };
+  uint8_t tag[6];
+  if (!c.exact(tag, 6)) return done(out_io_eof(o));
+  if (memcmp(tag, kMagic, 6) != 0)
+    return done(out_fail(o, MILZMA_XZ_ERROR, "Invalid XZ magic, expected [253, 55, 122, 88, 90, 0]"));
+  uint32_t flags, crc, digest;
+  {
+    const size_t from = c.pos;
+    if (!c.u16be(&flags)) return done(out_io_eof(o));
+    digest = milzma_crc32(c.p + from, 2);
+  }
+  if (!c.u32le(&crc)) return done(out_io_eof(o));
+  if (crc != digest)
+    return done(out_fail(o, MILZMA_XZ_ERROR, "Invalid header CRC32: expected 0x%08x but got 0x%08x", crc, digest));
+  int check = 0, footer_check = 0;
+  if ((r = stream_flags_parse(flags, &check, o))) return done(r);
+
+  size_t index_size = 0;
+  for (;;) {
+    const size_t start = c.pos;
+    uint8_t hsize;
+    if (!c.u8(&hsize)) return done(out_io_eof(o));
+    if (hsize == 0) {
+      if ((r = check_index(c, start, records, o))) return done(r);
+      index_size = c.pos - start;
+      break;
+    }
+    if ((r = read_block(ctx, c, start, output, check, records, hsize, decode, o))) return done(r);
+  }
+  if (!c.u32le(&crc)) return done(out_io_eof(o));
+  {
+    const size_t from = c.pos;
+    uint32_t backward;
+    if (!c.u32le(&backward)) return done(out_io_eof(o));
+    const uint32_t expect = uint32_t((backward + 1u) << 2);
+    if (uint32_t(index_size) != expect)
+      return done(out_fail(o, MILZMA_XZ_ERROR, "Invalid index size: expected %u but got %zu", expect, index_size));
+    if (!c.u16be(&flags)) return done(out_io_eof(o));
+    if ((r = stream_flags_parse(flags, &footer_check, o))) return done(r);
+    if (footer_check != check)
+      return done(out_fail(o, MILZMA_XZ_ERROR,
+                           "Flags in header (StreamFlags { check_method: %s }) does not match footer (StreamFlags { "
+                           "check_method: %s })",
+                           check_name(check), check_name(footer_check)));
+    digest = milzma_crc32(c.p + from, c.pos - from);
+  }
+  if (crc != digest)
+    return done(out_fail(o, MILZMA_XZ_ERROR, "Invalid footer CRC32: expected 0x%08x but got 0x%08x", crc, digest));
+  if (!c.exact(tag, 2)) return done(out_io_eof(o));
+  if (tag[0] != 0x59 || tag[1] != 0x5A) return done(out_fail(o, MILZMA_XZ_ERROR, "Invalid footer magic, expected [89, 90]"));
+  if (!c.eof()) return done(out_fail(o, MILZMA_XZ_ERROR, "Unexpected data after last XZ block"));
+  return done(MILZMA_OK);
+}
+
+// On-demand payload decode: one unit, reader limited only by the end of the file.
+PayloadFn live_decoder(milzma_ctx* ctx) {
+  return [ctx](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
+    milzma_unit u;
+    memset(&u, 0, sizeof u);
+    u.kind = MILZMA_KIND_LZMA2;
+    SingleDecode sd;
+    const size_t hint = cap_hint ? cap_hint + 64 : std::max<size_t>(1 << 16, in_len * 6);
+    if (!decode_single(ctx, u, in, in_len, hint, &sd)) return false;
+    p->res = sd.res;
+    sd.out.resize(size_t(std::min<uint64_t>(sd.res.out_len, sd.out.size())));
+    p->own = std::move(sd.out);
+    p->data = p->own.data();
+    return true;
+  };
+}
+
+// ---- batching: find the blocks of well-formed files up front through the Index ------------
+struct PlannedBlock {
+  size_t data_off;    // first byte of the block's LZMA2 payload within the file
+  size_t data_len;    // payload bytes according to the Index (unpadded - header - check)
+  uint64_t unpacked;  // uncompressed size according to the Index
+};
+
+size_t check_size(int check) {
+  switch (check) {
+    case CHECK_CRC32: return 4;
+    case CHECK_CRC64: return 8;
+    case CHECK_SHA256: return 32;
+    default: return 0;
+  }
+}
+
+// Best-effort parse of footer + Index.  Any oddity => false (the exact walk then decodes on
+// demand and reports whatever the reference would).
+bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blocks) {
+  blocks->clear();
+  if (n < 12 + 12 || (n & 3)) return false;
+  if (in[n - 2] != 0x59 || in[n - 1] != 0x5A) return false;
+  Cursor f{in, n - 12, n};
+  uint32_t crc, backward, flags;
+  if (!f.u32le(&crc) || !f.u32le(&backward) || !f.u16be(&flags)) return false;
+  if (milzma_crc32(in + n - 8, 6) != crc) return false;
+  if ((flags >> 8) != 0) return false;
+  const int check = int(flags & 0xFF);
+  if (check != CHECK_NONE && check != CHECK_CRC32 && check != CHECK_CRC64) return false;
+  const uint64_t index_size = (uint64_t(backward) + 1) << 2;
+  if (index_size + 24 > n) return false;
+  const size_t index_start = n - 12 - size_t(index_size);
+  Cursor c{in, index_start, n - 12};
+  uint8_t tag;
+  if (!c.u8(&tag) || tag != 0) return false;
+  uint64_t num;
+  if (get_multibyte(c, &num) || num > (n >> 2)) return false;
+  size_t pos = 12;
+  for (uint64_t i = 0; i < num; i++) {
+    uint64_t unpadded, unpacked;
+    if (get_multibyte(c, &unpadded) || get_multibyte(c, &unpacked)) return false;
+    if (pos >= index_start || unpadded > index_start - pos) return false;
+    const uint8_t hsize_byte = in[pos];
+    if (hsize_byte == 0) return false;
+    const size_t hsize = (size_t(hsize_byte) + 1) << 2;  // whole header incl. size byte and CRC32
+    if (uint64_t(hsize) + check_size(check) > unpadded) return false;
+    if (unpacked > MILZMA_MAX_UNIT_BYTES) return false;
+    blocks->push_back(PlannedBlock{pos + hsize, size_t(unpadded) - hsize - check_size(check), unpacked});
+    pos += size_t((unpadded + 3) & ~uint64_t(3));
+  }
+  return pos == index_start;
+}
+
+}  // namespace
+
+extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                          milzma_output* outs) {
+  // 1. plan: every block the Index of a file names becomes one LZMA2 unit of a single launch
+  struct Ref {
+    uint32_t file;
+    size_t data_off;
+  };
+  std::vector<milzma_unit> units;
+  std::vector<Ref> refs;
+  size_t in_total = 0, out_total = 0;
+  std::vector<size_t> file_in_off(n, 0);
+  for (uint32_t i = 0; i < n; i++) {
+    std::vector<PlannedBlock> blocks;
+    if (!plan_from_index(ins[i], in_lens[i], &blocks)) continue;
+    file_in_off[i] = in_total;
+    for (const auto& b : blocks) {
+      milzma_unit u;
+      memset(&u, 0, sizeof u);
+      u.kind = MILZMA_KIND_LZMA2;
+      u.in_off = in_total + b.data_off;
+      u.in_len = b.data_len;
+      u.out_off = out_total;
+      u.out_cap = round_up(size_t(b.unpacked) + 16, 256);
+      out_total += size_t(u.out_cap);
+      units.push_back(u);
+      refs.push_back(Ref{i, b.data_off});
+    }
+    if (!blocks.empty()) in_total += round_up(in_lens[i], 256);
+  }
+  std::vector<uint8_t> hin(in_total), hout(out_total);
+  std::vector<milzma_result> res(units.size());
+  if (!units.empty()) {
+    {
+      uint32_t last = UINT32_MAX;
+      for (const auto& r : refs)
+        if (r.file != last) {
+          memcpy(hin.data() + file_in_off[r.file], ins[r.file], in_lens[r.file]);
+          last = r.file;
+        }
+    }
+    if (milzma_decode_units_host(ctx, units.data(), uint32_t(units.size()), hin.data(), in_total, hout.data(), out_total,
+                                 res.data()) != MILZMA_OK) {
+      for (uint32_t i = 0; i < n; i++) {
+        out_reset(&outs[i]);
+        infra(ctx, &outs[i]);
+      }
+      return MILZMA_INFRA_ERROR;
+    }
+  }
+  // 2. the reference's walk per file; a payload decoded ahead is used only if it is provably what
+  //    an unlimited reader would have produced (clean status, consumed exactly the planned bytes,
+  //    no take() window cut short by the planned end); everything else is decoded on demand.
+  std::vector<std::unordered_map<size_t, size_t>> by_off(n);
+  for (size_t k = 0; k < refs.size(); k++) by_off[refs[k].file][refs[k].data_off] = k;
+  const PayloadFn live = live_decoder(ctx);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint8_t* base = ins[i];
+    PayloadFn fn = [&, base, i](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
+      const auto& m = by_off[i];
+      if (in >= base && in < base + in_lens[i]) {
+        const auto it = m.find(size_t(in - base));
+        if (it != m.end()) {
+          const size_t k = it->second;
+          const milzma_result& r = res[k];
+          if (r.status == MILZMA_ST_OK && r.in_consumed == units[k].in_len && !(r.chunks & 0x80000000u) &&
+              r.out_len <= units[k].out_cap) {
+            p->res = r;
+            p->data = hout.data() + units[k].out_off;
+            return true;
+          }
+        }
+      }
+      return live(in, in_len, cap_hint, p);
+    };
+    xz_walk(ctx, ins[i], in_lens[i], fn, &outs[i]);
+  }
+  return MILZMA_OK;
+}
+
+extern "C" int milzma_xz_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
+  const uint8_t* ins[1] = {in};
+  const size_t lens[1] = {in_len};
+  const int r = milzma_xz_decompress_batch(ctx, 1, ins, lens, out);
+  return r != MILZMA_OK ? r : out->kind;
+}

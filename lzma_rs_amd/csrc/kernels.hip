@@ -1,0 +1,36 @@
+// kernels.hip -- HIP translation unit: decode kernels for gfx950 and their launchers.
+#include "kernels.h"
+
+#include "decode_generic.hip.h"
+
+namespace milzma {
+
+hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
+                          const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, uint16_t* d_scratch,
+                          hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid(n), block(kWave);
+  switch (cls) {
+    case kLitLds3: {
+      const size_t lds = (M_SMALL_END + (0x300u << 3)) * sizeof(uint16_t);
+      hipLaunchKernelGGL(decode_generic_kernel<true>, grid, block, lds, stream, d_units, d_order, n, d_in, d_out,
+                         d_results, 3u, nullptr);
+      break;
+    }
+    case kLitLds4: {
+      const size_t lds = (M_SMALL_END + (0x300u << 4)) * sizeof(uint16_t);
+      hipLaunchKernelGGL(decode_generic_kernel<true>, grid, block, lds, stream, d_units, d_order, n, d_in, d_out,
+                         d_results, 4u, nullptr);
+      break;
+    }
+    default: {
+      const size_t lds = M_SMALL_END * sizeof(uint16_t);
+      hipLaunchKernelGGL(decode_generic_kernel<false>, grid, block, lds, stream, d_units, d_order, n, d_in, d_out,
+                         d_results, 0u, d_scratch);
+      break;
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace milzma

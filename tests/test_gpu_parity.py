@@ -1,0 +1,326 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bit-exact is the bar: error kind, full message, bytes delivered to the writer and the reader's
+final position must all equal what the oracle (= the reference's behaviour) produces.  Every test
+here needs a real MI355X and calls through libmilzma.so; nothing falls back to the oracle.
+"""
+import hashlib
+import lzma
+import os
+import random
+import struct
+
+import pytest
+
+import lzma_enc as E
+import lzma_rs_amd as M
+import oracle_py as orc
+from lzma_rs_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = M.Context(0)
+    yield c
+    c.close()
+
+
+def same(dec, ref, check_consumed=True):
+    """dec: lzma_rs_amd.Decoded, ref: oracle_py.OracleResult"""
+    assert (dec.kind, dec.msg) == (ref.kind, ref.msg), (dec, ref)
+    assert dec.data == ref.out, (len(dec.data), len(ref.out))
+    if check_consumed and ref.ok:
+        assert dec.in_consumed == ref.in_consumed, (dec, ref)
+
+
+# ---- the reference's own fixtures (tests/lzma.rs, tests/xz.rs) -------------------------------
+
+@pytest.mark.parametrize("name", ["hello.txt", "empty.txt", "foo.txt"])
+def test_lzma_fixtures(ctx, name):
+    comp = gold(name + ".lzma")
+    d = ctx.lzma(comp)
+    assert d.ok and d.data == gold(name)
+    same(d, orc.lzma_decompress(comp))
+
+
+def test_lzma_hugedict_and_edge_case(ctx):
+    d = ctx.lzma(gold("hugedict.txt.lzma"))
+    assert d.ok and d.data == gold("foo.txt")
+    d = ctx.lzma(gold("range-coder-edge-case.lzma"))
+    assert d.ok and len(d.data) == 3040092
+    assert hashlib.sha256(d.data).hexdigest() == \
+        "1bb292093eef1b21af67a24468ab40cfde2a616b2f859f90d3861568efd3b0f6"
+
+
+@pytest.mark.parametrize("name", ["foo.txt", "good-1-lzma2-1", "good-1-lzma2-2", "good-1-lzma2-3",
+                                  "good-1-lzma2-4", "hello.txt", "empty.txt", "block-check-crc32.txt"])
+def test_xz_fixtures(ctx, name):
+    comp = gold(name + ".xz")
+    d = ctx.xz(comp)
+    assert d.ok and d.data == gold(name)
+    same(d, orc.xz_decompress(comp))
+
+
+def test_xz_block_check_crc32_invalid(ctx):  # tests/xz.rs:123-146
+    buf = bytearray(gold("block-check-crc32.txt.xz"))
+    buf[0x54:0x58] = bytes([0x67, 0x45, 0x23, 0x01])
+    d = ctx.xz(bytes(buf))
+    assert d.msg == "xz error: Invalid footer CRC32: expected 0x01234567 but got 0x8b0d303e"
+    same(d, orc.xz_decompress(bytes(buf)))
+
+
+def test_crate_shaped_api(ctx):
+    import io
+    out = io.BytesIO()
+    M.lzma_decompress(io.BytesIO(gold("foo.txt.lzma")), out, ctx=ctx)
+    assert out.getvalue() == gold("foo.txt")
+    out = bytearray()
+    M.xz_decompress(gold("foo.txt.xz"), out, ctx=ctx)
+    assert bytes(out) == gold("foo.txt")
+    with pytest.raises(M.HeaderTooShort):
+        M.lzma_decompress(b"", bytearray(), ctx=ctx)
+    # known-size stream followed by other data: the reader stops where the reference stops
+    comp = W.compress_alone(b"hello hello hello hello", known_size=True)
+    inp = io.BytesIO(comp + b"TRAILING")
+    out = io.BytesIO()
+    M.lzma_decompress(inp, out, ctx=ctx)
+    ref = orc.lzma_decompress(comp + b"TRAILING")
+    assert out.getvalue() == ref.out and inp.tell() == ref.in_consumed
+
+
+# ---- options (tests/lzma.rs:237-356) ----------------------------------------------------------
+
+def test_option_matrix_and_memlimit(ctx):
+    data = b"Some data"
+    n = len(data)
+    US = M.UnpackedSize
+    cases = [
+        (E.dumb_encode(data, unpacked_size=n), None, (orc.READ_FROM_HEADER, None)),
+        (E.dumb_encode(data, write_size=False), M.Options(US.UseProvided(n)), (orc.USE_PROVIDED, n)),
+        (E.dumb_encode(data, unpacked_size=n), M.Options(US.ReadHeaderButUseProvided(n)),
+         (orc.READ_HEADER_BUT_USE_PROVIDED, n)),
+        (E.dumb_encode(data), M.Options(US.ReadHeaderButUseProvided(n)), (orc.READ_HEADER_BUT_USE_PROVIDED, n)),
+        (E.dumb_encode(data), M.Options(US.ReadHeaderButUseProvided(None)),
+         (orc.READ_HEADER_BUT_USE_PROVIDED, None)),
+    ]
+    for comp, opts, (mode, provided) in cases:
+        d = ctx.lzma(comp, opts)
+        assert d.ok and d.data == data
+        same(d, orc.lzma_decompress(comp, mode, provided))
+    comp = E.dumb_encode(data)
+    for memlimit in (0, 4, 8, 9, 100):
+        d = ctx.lzma(comp, M.Options(memlimit=memlimit))
+        same(d, orc.lzma_decompress(comp, memlimit=memlimit))
+    d = ctx.lzma(comp, M.Options(US.ReadHeaderButUseProvided(None), memlimit=0))
+    assert "exceeded memory limit of 0" in d.msg
+    # memlimit below the dictionary size, hit in the middle of a long match
+    big, _ = E.encode_lzma([("lit", 65)] + [("match", 200, 1)] * 40 + [("marker",)], dict_size=1 << 16)
+    for memlimit in (150, 4096, 5000):
+        same(ctx.lzma(big, M.Options(memlimit=memlimit)), orc.lzma_decompress(big, memlimit=memlimit))
+
+
+# ---- generated streams vs the oracle (and liblzma) --------------------------------------------
+
+@pytest.mark.parametrize("kind", ["text", "random", "repeat", "zeros"])
+def test_generated_streams_all_props(ctx, kind):
+    plain = W.make_plain(kind, 150_000, seed=11)
+    comps = []
+    for dict_size in (4096, 65536, 1 << 23):
+        for lc, lp, pb in [(3, 0, 2), (0, 2, 0), (4, 0, 4), (1, 3, 1), (0, 0, 0)]:
+            comp = W.compress_alone(plain, dict_size=dict_size, lc=lc, lp=lp, pb=pb)
+            comps.append(comp)
+            comps.append(comp[:5] + struct.pack("<Q", len(plain)) + comp[13:])  # known size
+    decs = ctx.lzma_batch(comps)
+    for comp, d in zip(comps, decs):
+        assert d.ok and d.data == plain
+        same(d, orc.lzma_decompress(comp))
+
+
+def test_symbol_streams_every_lclppb(ctx):
+    # liblzma refuses lc+lp > 4; the symbol encoder covers the whole 225-value props space
+    rng = random.Random(5)
+    comps = []
+    for trial in range(120):
+        lc, lp, pb = rng.choice([0, 3, 4, 8]), rng.choice([0, 1, 2, 4]), rng.choice([0, 1, 2, 4])
+        enc = E.LzmaSymbolEncoder(lc, lp, pb)
+        n = 0
+        for _ in range(rng.randint(0, 300)):
+            r = rng.random()
+            if n == 0 or r < 0.4:
+                s = ("lit", rng.randrange(256))
+            elif r < 0.7:
+                s = ("match", rng.randint(2, rng.choice([5, 20, 273])), rng.randint(1, n))
+            elif r < 0.85:
+                idx = rng.randint(0, 3)
+                s = ("rep", idx, rng.randint(2, 40)) if enc.rep[idx] + 1 <= n else ("lit", 7)
+            else:
+                s = ("shortrep",) if enc.rep[0] + 1 <= n else ("lit", 9)
+            enc.encode([s])
+            n = len(enc.out)
+        marker = rng.random() < 0.5
+        if marker:
+            enc.encode([("marker",)])
+        comps.append(E.lzma_header(lc, lp, pb, 1 << 20, None if marker else n) + enc.finish())
+    decs = ctx.lzma_batch(comps)
+    for comp, d in zip(comps, decs):
+        same(d, orc.lzma_decompress(comp))
+        assert d.ok
+
+
+def test_error_sites_match_oracle(ctx):
+    lits = [("lit", c) for c in b"abcdefgh"]
+    many = [("lit", i & 0xFF) for i in range(6000)]
+    cases = [
+        E.encode_lzma(lits + [("match", 4, 9), ("marker",)])[0],
+        E.encode_lzma(many + [("match", 4, 5000), ("marker",)], dict_size=4096)[0],
+        E.encode_lzma(lits + [("marker",)])[0] + b"\x00",
+        E.encode_lzma([("lit", 1), ("lit", 2), ("lit", 3), ("match", 7, 3)], unpacked_size=5)[0],
+        E.encode_lzma([("lit", 1)] * 5000 + [("match", 273, 3)], unpacked_size=5100, dict_size=4096)[0],
+        gold("hello.txt.lzma")[:17],
+        gold("foo.txt.lzma")[:30000],
+        gold("foo.txt.lzma")[:13],
+        b"\xff" + gold("hello.txt.lzma")[1:],
+        E.encode_lzma(lits, unpacked_size=None)[0],
+    ]
+    for n in range(14, 35):
+        cases.append(gold("hello.txt.lzma")[:n])
+    decs = ctx.lzma_batch(cases)
+    for comp, d in zip(cases, decs):
+        same(d, orc.lzma_decompress(comp))
+    for comp in cases[:4]:
+        same(ctx.lzma(comp), orc.lzma_decompress(comp))
+
+
+def test_corrupted_streams_same_verdict(ctx):  # fuzz/fuzz_targets/decompress_lzma.rs, compare_xz.rs
+    rng = random.Random(99)
+    base = gold("foo.txt.lzma")
+    cases = []
+    for _ in range(64):
+        b = bytearray(base)
+        for _ in range(rng.randint(1, 3)):
+            b[rng.randrange(13, len(b))] = rng.randrange(256)
+        cases.append(bytes(b))
+    for comp, d in zip(cases, ctx.lzma_batch(cases)):
+        same(d, orc.lzma_decompress(comp))
+    base = gold("foo.txt.xz")
+    cases = []
+    for _ in range(48):
+        b = bytearray(base)
+        for _ in range(rng.randint(1, 3)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        cases.append(bytes(b))
+    for comp, d in zip(cases, ctx.xz_batch(cases)):
+        same(d, orc.xz_decompress(comp))
+
+
+# ---- LZMA2 / XZ ---------------------------------------------------------------------------------
+
+def test_lzma2_streams(ctx):
+    plain = W.make_plain("text", 300_000, seed=3) + W.make_plain("random", 150_000, seed=4) + \
+        W.make_plain("text", 300_000, seed=5)
+    cases = []
+    for lc, lp, pb in [(3, 0, 2), (4, 0, 0), (0, 4, 4), (2, 2, 1)]:
+        filt = [{"id": lzma.FILTER_LZMA2, "dict_size": 65536, "lc": lc, "lp": lp, "pb": pb}]
+        cases.append(lzma.compress(plain, format=lzma.FORMAT_RAW, filters=filt))
+    stored = b"".join(E.lzma2_stored_chunk(plain[i:i + 0x10000], True)
+                      for i in range(0, len(plain), 0x10000)) + b"\x00"
+    cases.append(stored)
+    cases.append(b"\x00")
+    for comp, d in zip(cases, ctx.lzma2_batch(cases)):
+        ref = orc.lzma2_decompress(comp)
+        same(d, ref)
+        assert d.ok
+    same(ctx.lzma2(cases[0]), orc.lzma2_decompress(cases[0]))
+
+
+def test_lzma2_error_sites(ctx):
+    enc = E.LzmaSymbolEncoder(3, 0, 2).encode([("lit", 65), ("match", 3, 5)])
+    dist_err = E.lzma2_stored_chunk(b"0123456789", True) + \
+        E.lzma2_lzma_chunk(enc.finish(), 4, 0xE0, props=0x5D) + b"\x00"
+    enc = E.LzmaSymbolEncoder(3, 0, 2).encode([("lit", c) for c in b"abcdef"] + [("match", 2, 5)])
+    c1 = enc.take_chunk()
+    enc.stored(b"ZZ", True)
+    enc.encode([("lit", 0x41)])
+    c2 = enc.take_chunk()
+    match_err = E.lzma2_lzma_chunk(c1, 8, 0xE0, props=0x5D) + E.lzma2_stored_chunk(b"ZZ", True) + \
+        E.lzma2_lzma_chunk(c2, 1, 0x80) + b"\x00"
+    enc = E.LzmaSymbolEncoder(0, 0, 0).encode([("lit", c) for c in b"xyz"] + [("match", 5, 2)])
+    no_reset = E.lzma2_lzma_chunk(enc.finish(), 8, 0x80) + b"\x00"
+    enc = E.LzmaSymbolEncoder(3, 0, 2).encode([("lit", c) for c in b"hello"])
+    payload = enc.finish()
+    probe = orc.lzma2_decompress(E.lzma2_lzma_chunk(payload, 5, 0xE0, props=0x5D) + b"\x00")
+    used = probe.in_consumed - 1 - 6
+    leftover = bytes([0xE0]) + struct.pack(">H", 4) + struct.pack(">H", used + 3 - 1) + b"\x5d" + \
+        payload[:used] + E.lzma2_stored_chunk(b"!", False) + b"\x00"
+    size_mismatch = E.lzma2_lzma_chunk(payload, 4, 0xE0, props=0x5D) + b"\x00"
+    cases = [b"", b"\x03\x00\x00", b"\x01\x00", b"\x01\x00\x04abc", b"\xe0\x00\x04\x00",
+             b"\xe0\x00\x04\x00\x09", b"\xe0\x00\x04\x00\x09\xe1",
+             b"\xe0\x00\x04\x00\x09" + bytes([E.props_byte(4, 1, 0)]), b"\xe0\x00\x04\x00\x09\x5d\x00\x00",
+             dist_err, match_err, no_reset, leftover, size_mismatch]
+    for comp, d in zip(cases, ctx.lzma2_batch(cases)):
+        same(d, orc.lzma2_decompress(comp))
+
+
+def test_xz_multiblock_and_checks(ctx):
+    plain = W.make_plain("text", 500_000, seed=21) + W.make_plain("random", 100_000, seed=22) + \
+        W.make_plain("repeat", 300_000, seed=23)
+    filt = [{"id": lzma.FILTER_LZMA2, "dict_size": 65536, "lc": 3, "lp": 0, "pb": 2}]
+    cases = [W.compress_xz_blocks(plain, block_size=1 << 18, check=c) for c in ("crc64", "crc32", "none")]
+    cases.append(lzma.compress(plain, format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256, filters=filt))
+    cases.append(lzma.compress(plain, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=filt))
+    # damage in the middle of a block, a truncated file, trailing bytes: the planned units cannot all
+    # be trusted, the exact walk must still produce the reference's verdict
+    bad = bytearray(cases[0])
+    bad[len(bad) // 2] ^= 0xFF
+    cases.append(bytes(bad))
+    cases.append(cases[0][:-3])
+    cases.append(cases[0] + b"\x00\x00\x00\x00")
+    for comp, d in zip(cases, ctx.xz_batch(cases)):
+        same(d, orc.xz_decompress(comp))
+    assert ctx.xz(cases[0]).data == plain
+
+
+# ---- the unit-level ABI with device-resident buffers (what bench.py times) ---------------------
+
+def test_decode_units_device_resident(ctx):
+    import torch
+    comps, plains = W.make_lzma_batch(24, size=1 << 18, kind="text", dict_size=65536, known_size=True,
+                                      keep_plain=True)
+    n = len(comps)
+    units = (M.Unit * n)()
+    in_off, blobs = 0, []
+    for i, c in enumerate(comps):
+        u, hl = M.lzma_read_header(c)
+        payload = c[hl:]
+        u.in_off, u.in_len = in_off, len(payload)
+        u.out_off, u.out_cap = i * (1 << 18), 1 << 18
+        units[i] = u
+        pad = (-len(payload)) % 256
+        blobs.append(payload + bytes(pad))
+        in_off += len(payload) + pad
+    d_in = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(n << 18, dtype=torch.uint8, device="cuda")
+    res, ms, launches = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    assert launches == 1 and ms > 0
+    host = d_out.cpu().numpy().tobytes()
+    for i in range(n):
+        assert res[i].status == M.ST_OK and res[i].out_len == 1 << 18
+        assert host[i << 18:(i + 1) << 18] == plains[i]
+        ref = orc.lzma_decompress(comps[i])
+        assert res[i].in_consumed + 13 == ref.in_consumed
+    # a slice that is too small is reported, not overrun
+    units[0].out_cap = 1000
+    guard = d_out.clone()
+    res, _, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
+    assert res[0].status == M.ST_OUT_FULL and res[1].status == M.ST_OK
+    assert torch.equal(d_out[1000:1 << 18], guard[1000:1 << 18])

@@ -1,0 +1,106 @@
+"""CPU-only checks of the C ABI: the library loads, exports every symbol include/milzma.h
+declares, and its host-side logic (header parsing, CRCs, error rendering) matches the oracle.
+No compute call is made: there is no GPU here and the library has no CPU decode path."""
+import ctypes
+import os
+import re
+import struct
+
+import pytest
+
+import lzma_rs_amd as M
+import oracle_py as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "milzma.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(milzma_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    L = M.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libmilzma.so does not export " + name
+    assert set(M.EXPORTS) == declared
+    assert L.milzma_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(M.Unit) == 56
+    assert ctypes.sizeof(M.Result) == 48
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(M.InfraError):
+        M.Context(0)
+    with pytest.raises(M.InfraError):
+        M.lzma_decompress(open(os.path.join(GOLD, "hello.txt.lzma"), "rb").read(), bytearray())
+
+
+def test_read_header_matches_oracle():
+    hello = open(os.path.join(GOLD, "hello.txt.lzma"), "rb").read()
+    u, hl = M.lzma_read_header(hello)
+    assert (u.lc, u.lp, u.pb, u.dict_size, u.unpacked_size, hl) == (3, 0, 2, 0x800000, M.SIZE_UNKNOWN, 13)
+    assert u.kind == M.KIND_RAW_LZMA and u.memlimit == M.NO_LIMIT
+    # dict sizes below 0x1000 are raised to 0x1000 (lzma.rs:117-124)
+    u, _ = M.lzma_read_header(b"\x5d" + struct.pack("<I", 5) + struct.pack("<Q", 77))
+    assert u.dict_size == 0x1000 and u.unpacked_size == 77
+    for n in range(0, 13):
+        with pytest.raises(M.HeaderTooShort) as e:
+            M.lzma_read_header(hello[:n])
+        assert str(e.value) == orc.lzma_decompress(hello[:n]).msg
+    with pytest.raises(M.LzmaError) as e:
+        M.lzma_read_header(b"\xff" + hello[1:])
+    assert str(e.value) == "lzma error: LZMA header invalid properties: 255 must be < 225"
+    # option matrix (options.rs:22-43)
+    opts = M.Options(unpacked_size=M.UnpackedSize.UseProvided(9), memlimit=5)
+    u, hl = M.lzma_read_header(hello, opts)
+    assert hl == 5 and u.unpacked_size == 9 and u.memlimit == 5
+    opts = M.Options(unpacked_size=M.UnpackedSize.ReadHeaderButUseProvided(None))
+    u, hl = M.lzma_read_header(b"\x5d" + struct.pack("<I", 1 << 16) + struct.pack("<Q", 1234), opts)
+    assert hl == 13 and u.unpacked_size == M.SIZE_UNKNOWN
+    for props in range(225):
+        u, _ = M.lzma_read_header(bytes([props]) + hello[1:])
+        assert u.lc + 9 * (u.lp + 5 * u.pb) == props
+
+
+def test_crc_matches_oracle():
+    data = open(os.path.join(GOLD, "foo.txt"), "rb").read()
+    for cut in (0, 1, 7, 8, 9, 1000, len(data)):
+        assert M.crc32(data[:cut]) == orc.crc32(data[:cut])
+        assert M.crc64(data[:cut]) == orc.crc64(data[:cut])
+    assert M.crc32(b"123456789") == 0xCBF43926
+    assert M.crc64(b"123456789") == 0x995DC9BBDF1939FA
+
+
+def test_result_messages_are_the_reference_strings():
+    def msg(status, a=0, b=0, kind=M.KIND_RAW_LZMA):
+        r = M.Result()
+        r.status, r.err_a, r.err_b = status, a, b
+        return M.result_message(r, kind)
+
+    assert msg(0) == (M.OK, "")
+    assert msg(1) == (M.LZMA_ERROR, "lzma error: LZMA stream too short: failed to fill whole buffer")
+    assert msg(1, kind=M.KIND_LZMA2) == (M.LZMA_ERROR, "lzma error: LZMA input too short: failed to fill whole buffer")
+    assert msg(2) == (M.IO_ERROR, "io error: failed to fill whole buffer")
+    assert msg(3, 5000, 4096)[1] == "lzma error: Match distance 5000 is beyond dictionary size 4096"
+    assert msg(4, 5, 2)[1] == "lzma error: Match distance 5 is beyond output size 2"
+    assert msg(5, 5000, 4096)[1] == "lzma error: LZ distance 5000 is beyond dictionary size 4096"
+    assert msg(6, 9, 8)[1] == "lzma error: LZ distance 9 is beyond output size 8"
+    assert msg(7, 0)[1] == "lzma error: exceeded memory limit of 0"
+    assert msg(8)[1] == "lzma error: Found end-of-stream marker but more bytes are available"
+    assert msg(9, 5, 10)[1] == "lzma error: Expected unpacked size of 5 but decompressed to 10"
+    assert msg(16)[1] == "lzma error: LZMA2 expected new status: failed to fill whole buffer"
+    assert msg(17, 3)[1] == "lzma error: LZMA2 invalid status 3, must be 0, 1, 2 or >= 128"
+    assert msg(18)[1] == "lzma error: LZMA2 expected unpacked size: failed to fill whole buffer"
+    assert msg(19)[1] == "lzma error: LZMA2 expected packed size: failed to fill whole buffer"
+    assert msg(20)[1] == "lzma error: LZMA2 expected new properties: failed to fill whole buffer"
+    assert msg(21, 225)[1] == "lzma error: LZMA2 invalid properties: 225 must be < 225"
+    assert msg(22, 4, 1)[1] == "lzma error: LZMA2 invalid properties: lc + lp (4 + 1) must be <= 4"
+    assert msg(23, 5)[1] == "lzma error: LZMA2 expected 5 uncompressed bytes: failed to fill whole buffer"
+    assert msg(32)[0] == M.INFRA_ERROR
