@@ -1,0 +1,118 @@
+"""Multi-GPU plumbing: one process per GPU, streams partitioned across ranks.
+
+LZMA streams are independent (every public entry point of the reference builds a fresh
+DecoderState: src/lib.rs:57-59, src/decode/lzma2.rs:23-34), so the decode path itself needs no
+collective: rank r decodes its own contiguous range of units.  torch.distributed (backend "nccl"
+= RCCL over xGMI on ROCm, "gloo" in the CPU tests) is used only for the rendezvous, the
+max-over-ranks timing, and -- optionally -- for moving compressed input out from rank 0
+(`scatter_inputs`) and decoded output back (`gather_outputs`).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    """Initialise the default process group when WORLD_SIZE > 1. Returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous range [lo, hi) of the batch that `rank` decodes; sizes differ by at most one."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_bytes(sizes, world):
+    """Greedy longest-processing-time partition of units by (compressed) size.
+    Returns a list of index lists, one per rank; every unit appears exactly once."""
+    order = sorted(range(len(sizes)), key=lambda i: -sizes[i])
+    loads = [0] * world
+    parts = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: loads[k])
+        parts[r].append(i)
+        loads[r] += sizes[i]
+    for p in parts:
+        p.sort()
+    return parts
+
+
+def barrier_sync(device=None):
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a python float (the step time every rank must agree on)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def scatter_inputs(chunks, device):
+    """Rank 0 holds `chunks` (list of uint8 tensors, one per rank, any lengths); every rank gets
+    its own chunk on `device`.  Lengths travel first, then the payloads as point-to-point sends
+    (xGMI is point-to-point: one send per peer is the natural pattern)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    if world == 1:
+        return chunks[0].to(device)
+    lens = torch.zeros(world, dtype=torch.int64, device=device)
+    if rank == 0:
+        lens = torch.tensor([c.numel() for c in chunks], dtype=torch.int64, device=device)
+    dist.broadcast(lens, src=0)
+    mine = torch.empty(int(lens[rank].item()), dtype=torch.uint8, device=device)
+    if rank == 0:
+        reqs = [dist.isend(chunks[r].to(device), dst=r) for r in range(1, world)]
+        mine.copy_(chunks[0].to(device))
+        for q in reqs:
+            q.wait()
+    else:
+        dist.recv(mine, src=0)
+    return mine
+
+
+def gather_outputs(local_out, device):
+    """All ranks contribute a uint8 tensor (lengths may differ); rank 0 receives the list."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    if world == 1:
+        return [local_out]
+    n = torch.tensor([local_out.numel()], dtype=torch.int64, device=device)
+    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(lens, n)
+    if rank == 0:
+        outs = [local_out]
+        for r in range(1, world):
+            buf = torch.empty(int(lens[r].item()), dtype=torch.uint8, device=device)
+            dist.recv(buf, src=r)
+            outs.append(buf)
+        return outs
+    dist.send(local_out, dst=0)
+    return None

@@ -71,6 +71,10 @@ def _one_stream(args):
     return compress_alone(plain, dict_size=dict_size, known_size=known_size), plain
 
 
+def _one_stream_compressed(args):
+    return _one_stream(args)[0]
+
+
 def make_lzma_batch(n_distinct, size=1 << 20, kind="text", dict_size=65536, known_size=True,
                     processes=None, keep_plain=False):
     """n_distinct .lzma streams (seed 0xC0FFEE ^ i), compressed on `processes` host cores.

@@ -1309,20 +1309,31 @@ typedef struct {
 
 static void *bench_worker(void *vp) {
   bench_arg_t *a = (bench_arg_t *)vp;
+  sink_t out = {0, 0, 0}; /* reused across streams: one allocation per thread, like a caller
+                             that hands the same Vec<u8> to lzma_decompress again and again */
   for (;;) {
     uint32_t i;
-    orc_result res;
+    reader_t rd;
+    err_t e;
+    params_t params;
+    orc_options dflt;
     pthread_mutex_lock(a->mu);
     i = (*a->next)++;
     pthread_mutex_unlock(a->mu);
     if (i >= a->n) break;
-    memset(&res, 0, sizeof res);
-    if (orc_lzma_decompress(a->in_base + a->in_off[i], (size_t)a->in_len[i], NULL, &res))
+    rd.p = a->in_base + a->in_off[i];
+    rd.pos = 0;
+    rd.end = (size_t)a->in_len[i];
+    memset(&e, 0, sizeof e);
+    orc_default_options(&dflt);
+    out.len = 0;
+    if (read_header(&rd, &dflt, &params, &e) ||
+        lzma_decoder_decompress(&params, 0, 0, &rd, &out, &e))
       a->failed = 1;
-    a->bytes += (int64_t)res.out_len;
-    a->check ^= orc_crc32(res.out, res.out_len) + i;
-    orc_free(res.out);
+    a->bytes += (int64_t)out.len;
+    a->check ^= orc_crc32(out.data, out.len) + i;
   }
+  free(out.data);
   return NULL;
 }
 
