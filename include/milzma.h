@@ -89,7 +89,8 @@ enum {
   /* not reference errors: conditions of this implementation, resolved by the host layer */
   MILZMA_ST_OUT_FULL = 32,   /* out_cap reached before the stream ended (grow the slice and retry)     */
   MILZMA_ST_NEED_LCLP = 33,  /* unit needs a literal table for lc+lp = {a} larger than its launch class */
-  MILZMA_ST_BAD_UNIT = 34    /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
+  MILZMA_ST_BAD_UNIT = 34,   /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
+  MILZMA_ST_NEED_GENERIC = 35 /* props outside the fast kernel's specialisation: rerun in the generic one */
 };
 
 typedef struct milzma_result {

@@ -379,20 +379,6 @@ struct GenericDecoder {
   }
 };
 
-// Shared tail: lane 0 publishes the unit's result.
-__device__ __forceinline__ void store_result(milzma_result* res, uint32_t status, uint32_t chunks, uint64_t out_len,
-                                    uint64_t out_flushed, uint64_t in_consumed, uint64_t a, uint64_t b) {
-  if (threadIdx.x == 0) {
-    res->status = status;
-    res->chunks = chunks;
-    res->out_len = out_len;
-    res->out_flushed = out_flushed;
-    res->in_consumed = in_consumed;
-    res->err_a = a;
-    res->err_b = b;
-  }
-}
-
 // lit_cap_lclp: largest lc+lp whose literal table fits this launch's LDS (LIT_IN_LDS), else unused.
 // lit_scratch : HBM, (0x300 << 12) u16 per block, used when !LIT_IN_LDS.
 template <bool LIT_IN_LDS>

@@ -15,6 +15,25 @@ namespace milzma {
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kTop = 1u << 24;
 
+// Raw buffer resources: per-lane predication without control flow.  A lane whose offset is
+// out of range (we use 0xFFFFFFFF) loads 0 / has its store dropped, so "only some lanes touch
+// memory" needs neither a divergent branch nor an EXEC dance -- which also keeps hipcc's
+// uniformity analysis from declaring the surrounding loops' scalars divergent.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t kOob = 0xFFFFFFFFu;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_load_u8(rsrc_t r, uint32_t off) {
+  return uint32_t(__builtin_amdgcn_raw_buffer_load_b8(r, off, 0, 0));
+}
+__device__ __forceinline__ uint32_t buf_load_u32(rsrc_t r, uint32_t off) {
+  return uint32_t(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store_u8(rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b8(uint8_t(v), r, off, 0, 0);
+}
+
 // Wave-uniform read of one lane's register.
 __device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t lane) {
   return __builtin_amdgcn_readlane(v, lane);
@@ -72,6 +91,20 @@ __device__ __forceinline__ bool reader_eof(const Reader& r) { return r.v >= r.li
 __device__ __forceinline__ uint32_t small_mod(uint32_t i, uint32_t d, float rcp_d) {
   const uint32_t q = uint32_t((float(i) + 0.5f) * rcp_d);
   return i - q * d;
+}
+
+// Shared tail: publishes the unit's result.  Every lane stores the same values to the same
+// addresses: a lane-dependent branch anywhere in the kernel makes hipcc structurise the whole
+// control flow graph (every uniform branch turns into a mask-and-Flow-block sequence).
+__device__ __forceinline__ void store_result(milzma_result* res, uint32_t status, uint32_t chunks, uint64_t out_len,
+                                             uint64_t out_flushed, uint64_t in_consumed, uint64_t a, uint64_t b) {
+  res->status = status;
+  res->chunks = chunks;
+  res->out_len = out_len;
+  res->out_flushed = out_flushed;
+  res->in_consumed = in_consumed;
+  res->err_a = a;
+  res->err_b = b;
 }
 
 }  // namespace milzma

@@ -45,6 +45,7 @@ struct milzma_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   uint32_t last_launches = 0;
+  bool use_fast = true;  // MILZMA_KERNEL=generic turns the lane-resident-model kernel off (A/B runs, tests)
 };
 
 namespace {
@@ -100,6 +101,7 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   }
   auto* ctx = new milzma_ctx();
   ctx->device = device;
+  if (const char* k = getenv("MILZMA_KERNEL")) ctx->use_fast = strcmp(k, "generic") != 0;
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
       !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
     delete ctx;
@@ -146,9 +148,12 @@ namespace {
 
 constexpr uint32_t kSpillBatch = 32;  // blocks per launch of the HBM-spill class (6 MiB scratch each)
 
-LitClass classify(const milzma_unit& u) {
-  if (u.kind != MILZMA_KIND_RAW_LZMA) return kLitLds3;  // LZMA2 starts small, NEED_LCLP promotes it
+LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
+  // LZMA2 units start in the cheapest class; NEED_GENERIC / NEED_LCLP promote them when a chunk
+  // switches to properties that class is not built for.
+  if (u.kind != MILZMA_KIND_RAW_LZMA) return ctx->use_fast ? kFast : kLitLds3;
   const uint32_t lclp = uint32_t(u.lc) + u.lp;
+  if (ctx->use_fast && u.pb <= 2 && lclp <= 3) return kFast;
   if (lclp <= 3) return kLitLds3;
   if (lclp <= 4) return kLitLds4;
   return kLitSpill;
@@ -167,11 +172,10 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
-    if (!hip_ok(ctx,
-                launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
-                               static_cast<uint16_t*>(ctx->scratch.p), stream),
-                "kernel launch"))
-      return false;
+    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream)
+                                       : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
+                                                        static_cast<uint16_t*>(ctx->scratch.p), stream);
+    if (!hip_ok(ctx, le, "kernel launch")) return false;
     if (!hip_ok(ctx, hipEventRecord(ctx->ev1, stream), "hipEventRecord")) return false;
     if (!hip_ok(ctx, hipEventSynchronize(ctx->ev1), "hipEventSynchronize")) return false;
     float ms = 0.f;
@@ -200,7 +204,7 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
   std::vector<uint32_t> order[kNumLitClasses];
-  for (uint32_t i = 0; i < n; i++) order[classify(units[i])].push_back(i);
+  for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
   std::vector<uint32_t> flat;
   flat.reserve(n);
   uint32_t base[kNumLitClasses];
@@ -231,18 +235,23 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
       !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
     return MILZMA_INFRA_ERROR;
 
-  // LZMA2 units that met props with lc+lp == 4 mid-stream: run them again in the bigger class.
-  std::vector<uint32_t> again;
-  for (uint32_t i = 0; i < n; i++)
-    if (results[i].status == MILZMA_ST_NEED_LCLP && results[i].err_a <= 4 && classify(units[i]) == kLitLds3)
-      again.push_back(i);
-  if (!again.empty()) {
+  // Promotions: LZMA2 units whose chunks switched to properties outside their class's reach run
+  // again, from the start, in the next class up (fast -> generic/LDS3 -> generic/LDS4).
+  for (int round = 0; round < 2; round++) {
+    std::vector<uint32_t> again;
+    LitClass next = kLitLds3;
+    for (uint32_t i = 0; i < n; i++) {
+      if (round == 0 && results[i].status == MILZMA_ST_NEED_GENERIC) again.push_back(i);
+      if (round == 1 && results[i].status == MILZMA_ST_NEED_LCLP && results[i].err_a <= 4) again.push_back(i);
+    }
+    if (round == 1) next = kLitLds4;
+    if (again.empty()) continue;
     if (!hip_ok(ctx,
                 hipMemcpyAsync(static_cast<uint32_t*>(ctx->order.p) + n, again.data(), again.size() * sizeof(uint32_t),
                                hipMemcpyHostToDevice, stream),
                 "H2D order"))
       return MILZMA_INFRA_ERROR;
-    if (!launch_class(ctx, kLitLds4, again, n, static_cast<const uint8_t*>(d_in), static_cast<uint8_t*>(d_out), stream))
+    if (!launch_class(ctx, next, again, n, static_cast<const uint8_t*>(d_in), static_cast<uint8_t*>(d_out), stream))
       return MILZMA_INFRA_ERROR;
     if (!hip_ok(ctx,
                 hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
@@ -329,6 +338,7 @@ extern "C" int milzma_result_message(const milzma_result* r, uint32_t unit_kind,
     case MILZMA_ST_OUT_FULL: return render(msg, cap, MILZMA_INFRA_ERROR, "output slice too small");
     case MILZMA_ST_NEED_LCLP: return render(msg, cap, MILZMA_INFRA_ERROR, "literal table class too small for lc+lp=%llu", a);
     case MILZMA_ST_BAD_UNIT: return render(msg, cap, MILZMA_INFRA_ERROR, "bad unit descriptor");
+    case MILZMA_ST_NEED_GENERIC: return render(msg, cap, MILZMA_INFRA_ERROR, "properties outside the fast kernel's class");
     default: return render(msg, cap, MILZMA_INFRA_ERROR, "unknown status %u", r->status);
   }
 }

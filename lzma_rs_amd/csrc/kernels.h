@@ -7,12 +7,13 @@
 
 namespace milzma {
 
-// Launch classes of the generic kernel: how much of the model lives in LDS.
+// Launch classes: which kernel, and for the generic one how much of the model lives in LDS.
 enum LitClass : int {
-  kLitLds3 = 0,   // literal table for lc+lp <= 3 in LDS (15 984 B per wave: 10 waves per CU)
-  kLitLds4 = 1,   // lc+lp <= 4 in LDS (28 272 B per wave: 5 waves per CU)
-  kLitSpill = 2,  // literal table in HBM scratch (lc+lp up to 12), small tables in LDS
-  kNumLitClasses = 3
+  kFast = 0,      // decode_fast_kernel: pb <= 2, lc+lp <= 3, model in VGPR lanes, 16 waves per CU
+  kLitLds3 = 1,   // generic kernel, literal table for lc+lp <= 3 in LDS (15 984 B per wave: 10 waves per CU)
+  kLitLds4 = 2,   // generic kernel, lc+lp <= 4 in LDS (28 272 B per wave: 5 waves per CU)
+  kLitSpill = 3,  // generic kernel, literal table in HBM scratch (lc+lp up to 12), small tables in LDS
+  kNumLitClasses = 4
 };
 
 // bytes of HBM scratch one block of the spill class needs
@@ -22,5 +23,9 @@ constexpr size_t kSpillBytesPerBlock = size_t(0x300u << 12) * sizeof(uint16_t);
 hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
                           const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, uint16_t* d_scratch,
                           hipStream_t stream);
+
+// The lane-resident-model kernel (pb <= 2, lc + lp <= 3): no LDS, 16 waves per CU.
+hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in,
+                       uint8_t* d_out, milzma_result* d_results, hipStream_t stream);
 
 }  // namespace milzma

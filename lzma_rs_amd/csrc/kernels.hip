@@ -2,6 +2,7 @@
 #include "kernels.h"
 
 #include "decode_generic.hip.h"
+#include "decode_fast.hip.h"
 
 namespace milzma {
 
@@ -30,6 +31,13 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
       break;
     }
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in,
+                       uint8_t* d_out, milzma_result* d_results, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(decode_fast_kernel, dim3(n), dim3(kWave), 0, stream, d_units, d_order, n, d_in, d_out, d_results);
   return hipGetLastError();
 }
 

@@ -27,11 +27,15 @@ def gold(name):
         return f.read()
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["fast", "generic"])
+def ctx(request):
+    """Every test runs twice: with the lane-resident-model kernel enabled (units outside its class
+    still fall through to the generic kernel) and with the generic kernel only."""
+    os.environ["MILZMA_KERNEL"] = request.param
     c = M.Context(0)
     yield c
     c.close()
+    os.environ.pop("MILZMA_KERNEL", None)
 
 
 def same(dec, ref, check_consumed=True):
