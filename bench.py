@@ -34,6 +34,20 @@ from lzma_rs_amd import workloads as W  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 
 
+def effective_cores():
+    """CPUs this process can actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _compress_range(job):
     """Worker: compress streams [lo, hi) and park them in one /dev/shm file (returning bulk data
     through the pool's pipes would serialise on the parent)."""
@@ -139,8 +153,9 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 20, help="plaintext bytes per stream")
     ap.add_argument("--dict", type=int, default=1 << 16, help="LZMA dictionary size")
     ap.add_argument("--kind", default="text", choices=["text", "random", "repeat", "zeros"])
-    ap.add_argument("--distinct", type=int, default=0,
-                    help="distinct streams to compress per GPU (0 = all; fewer are tiled)")
+    ap.add_argument("--distinct", type=int, default=512,
+                    help="distinct streams compressed per GPU (0 = all; fewer are tiled over the slots, each "
+                         "slot still reads its own copy of the input and writes its own output slice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="streams in the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-verify", action="store_true")
@@ -149,7 +164,7 @@ def main():
     rank, local_rank, world = D.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     procs = max(1, cores // world)
     n = args.streams
     distinct = args.distinct or n
@@ -159,7 +174,7 @@ def main():
                                                  first_index=rank * n, processes=procs)
     cpu_line = None
     if world == 1 and not args.no_cpu_baseline:
-        sample = args.cpu_sample or min(1024, cores * 4)
+        sample = args.cpu_sample or min(1024, cores * 24)
         cpu_line = cpu_baseline(sample, args.size, args.kind, args.dict, cores)
 
     D.init()

@@ -9,7 +9,7 @@ def main(path, out=sys.stdout):
     db = sqlite3.connect(path)
     cur = db.cursor()
     print("# rocprofv3 --kernel-trace --stats summary of %s" % path, file=out)
-    print("%-12s %8s %16s %16s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"), file=out)
+    print("%-12s %8s %16s %16s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"), file=out)
     for name, calls, total, avg, pct in cur.execute("select * from top_kernels"):
         print("%s\n%-12s %8d %16.0f %16.0f %8.3f" % (name, "", calls, total, avg, pct), file=out)
     print("\n# dispatches (ns)", file=out)
