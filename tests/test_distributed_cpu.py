@@ -1,0 +1,87 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU plumbing: partitioning, the max-over-ranks step
+time, and the optional input scatter / output gather around the (collective-free) decode."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lzma_rs_amd import distributed as D  # noqa: E402
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = D.shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n
+                seen.extend(range(lo, hi))
+            assert seen == list(range(n))
+            sizes = [D.shard_range(n, r, world)[1] - D.shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_by_bytes_balances():
+    sizes = [(i * 7919) % 1000 + 1 for i in range(500)]
+    parts = D.shard_by_bytes(sizes, 4)
+    assert sorted(i for p in parts for i in p) == list(range(500))
+    loads = [sum(sizes[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(sizes)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = D.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    dev = torch.device("cpu")
+    # step time agreed by all ranks = the slowest rank's
+    t = D.max_over_ranks(1.0 + rank, dev)
+    total = D.sum_over_ranks(10 * (rank + 1), dev)
+    # rank 0 scatters one compressed chunk per rank; every rank "decodes" (here: transforms) its own
+    # chunk without talking to anyone; rank 0 gathers the variable-length outputs
+    chunks = None
+    if rank == 0:
+        chunks = [torch.arange(100 + 50 * k, dtype=torch.uint8) for k in range(world)]
+    mine = D.scatter_inputs(chunks if rank == 0 else [None] * world, dev)
+    out = (mine.to(torch.int16) * 2 % 251).to(torch.uint8).repeat(rank + 1)
+    D.barrier_sync(None)
+    gathered = D.gather_outputs(out, dev)
+    ok = True
+    if rank == 0:
+        for k in range(world):
+            want = (torch.arange(100 + 50 * k, dtype=torch.int16) % 256 * 2 % 251).to(torch.uint8).repeat(k + 1)
+            ok = ok and torch.equal(gathered[k], want)
+    q.put((rank, t, total, mine.numel(), ok))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, t, total, n, ok in res:
+        assert t == 2.0 and total == 30.0 and n == 100 + 50 * rank and ok
