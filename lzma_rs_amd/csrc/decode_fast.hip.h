@@ -44,6 +44,7 @@ struct FastDecoder {
   uint32_t range;  // SGPR
   uint32_t code;   // VGPR, same value in every lane
   uint32_t eof;    // sticky: normalize() wanted a byte past the limit
+  uint32_t k2048, k31;  // VGPR constants for the probability update (v_cndmask cannot take two scalars)
   // ---- model: one probability per lane -----------------------------------------------------------
   uint32_t m_ismatch;   // [state*4 + pos_state] (48); 48 len.choice 49 len.choice2 50 replen.choice 51 replen.choice2
   uint32_t m_rep;       // [k*12 + state], k: 0 is_rep, 1 is_rep_g0, 2 is_rep_g1, 3 is_rep_g2
@@ -152,7 +153,7 @@ struct FastDecoder {
   }
 
   // RangeDecoder::decode_bit (rangecoder.rs:92-120) on the probability held by one lane of T.
-  // Returns 2*sym + bit.  10 scalar + 10 vector instructions, no branch.  The lane is
+  // Returns 2*sym + bit.  10 scalar + 8 vector instructions, no branch.  The lane is
   //   LANE_IS_A:   a            LANE_A_PLUS_B: a + b            LANE_A_AND_63: a & 63
   // computed inside the asm: left to hipcc, some of these scalar adds get moved to the VALU and the
   // result handed to v_readlane as a VGPR, which does not assemble.
@@ -165,11 +166,9 @@ struct FastDecoder {
   "v_subrev_u32 %[vt], %[sb], %[code]\n\t"                                                                   \
   "v_min_u32 %[code], %[code], %[vt]\n\t"         /* code -= bound if bit */                                 \
   "s_lshl_b64 exec, 1, %[ln]\n\t"                 /* only the owning lane updates its probability */         \
-  "v_cndmask_b32 %[vt], 31, 0, vcc\n\t"                                                                      \
-  "v_cndmask_b32 %[vu], 64, 0, vcc\n\t"                                                                      \
-  "v_add_u32 %[vt], %[T], %[vt]\n\t"                                                                         \
-  "v_lshrrev_b32 %[vt], 5, %[vt]\n\t"                                                                        \
-  "v_sub_u32 %[vt], %[vu], %[vt]\n\t"                                                                        \
+  "v_cndmask_b32 %[vt], %[k2048], %[k31], vcc\n\t"  /* K = bit ? 31 : 2048 */                          \
+  "v_sub_u32 %[vt], %[vt], %[T]\n\t"                                                                         \
+  "v_ashrrev_i32 %[vt], 5, %[vt]\n\t"             /* (K - p) >> 5 arithmetic: -(p >> 5) or (2048 - p) >> 5 */ \
   "v_add_u32 %[T], %[T], %[vt]\n\t"               /* bit ? p - (p >> 5) : p + ((2048 - p) >> 5) */           \
   "s_mov_b64 exec, -1\n\t"                                                                                   \
   "s_sub_u32 %[sr1], %[range], %[sb]\n\t"                                                                    \
@@ -178,24 +177,24 @@ struct FastDecoder {
   "s_addc_u32 %[sym], %[sym], %[sym]"
   template <int MODE>
   __device__ __forceinline__ uint32_t bitm(uint32_t& T, uint32_t a, uint32_t b, uint32_t sym) {
-    uint32_t sp, sb, sr1, vt, vu, ln;
+    uint32_t sp, sb, sr1, vt, ln;
     if (MODE == LANE_IS_A) {
       asm volatile(MILZMA_BIT_BODY
                    : [T] "+v"(T), [range] "+s"(range), [code] "+v"(code), [sym] "+s"(sym), [sp] "=&s"(sp),
-                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt), [vu] "=&v"(vu)
-                   : [ln] "s"(a)
+                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt)
+                   : [ln] "s"(a), [k2048] "v"(k2048), [k31] "v"(k31)
                    : "vcc", "scc");
     } else if (MODE == LANE_A_PLUS_B) {
       asm volatile("s_add_u32 %[ln], %[a], %[b]\n\t" MILZMA_BIT_BODY
                    : [T] "+v"(T), [range] "+s"(range), [code] "+v"(code), [sym] "+s"(sym), [sp] "=&s"(sp),
-                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt), [vu] "=&v"(vu), [ln] "=&s"(ln)
-                   : [a] "s"(a), [b] "s"(b)
+                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt), [ln] "=&s"(ln)
+                   : [a] "s"(a), [b] "s"(b), [k2048] "v"(k2048), [k31] "v"(k31)
                    : "vcc", "scc");
     } else {
       asm volatile("s_and_b32 %[ln], %[a], 63\n\t" MILZMA_BIT_BODY
                    : [T] "+v"(T), [range] "+s"(range), [code] "+v"(code), [sym] "+s"(sym), [sp] "=&s"(sp),
-                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt), [vu] "=&v"(vu), [ln] "=&s"(ln)
-                   : [a] "s"(a)
+                     [sb] "=&s"(sb), [sr1] "=&s"(sr1), [vt] "=&v"(vt), [ln] "=&s"(ln)
+                   : [a] "s"(a), [k2048] "v"(k2048), [k31] "v"(k31)
                    : "vcc", "scc");
     }
     if (__builtin_expect(range < kTop, 0)) normalize();
@@ -608,6 +607,7 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   d.mb = kNoByte;
   d.range = 0;
   d.set_code(0);
+  asm volatile("v_mov_b32 %0, 0x800\n\tv_mov_b32 %1, 31" : "=v"(d.k2048), "=v"(d.k31));
   {
     const uint8_t* p = in_base + u.in_off;
     const uint32_t a0 = uint32_t(reinterpret_cast<uintptr_t>(p) & 63u);
