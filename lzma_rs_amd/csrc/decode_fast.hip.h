@@ -72,6 +72,13 @@ struct FastDecoder {
   uint32_t lc, lp, pb;
   uint32_t state, rep0, rep1, rep2, rep3;
   uint32_t prev, mb;  // last output byte / byte after the last match source; kNoByte = not known
+  // A short match is split in two: its load is issued when the match is decoded, its store (and the
+  // extraction of prev / mb from the loaded lanes) happens when the next symbol needs them or the
+  // next match is about to be copied.  The ~1.5 us HBM/MALL latency of the load then overlaps with
+  // decoding the next symbol instead of stalling the wave (rocprof: s_waitcnt was 28 % of wave time).
+  uint32_t pend_n;    // bytes of the pending match (0 = none); its lanes 0..pend_n hold src[0..pend_n]
+  uint32_t pend_pos;  // where they go
+  uint32_t pend_val;  // VGPR
   uint32_t status;
   milzma_result* res;  // error arguments go straight to the result record (keeps them out of SGPRs)
 
@@ -296,7 +303,18 @@ struct FastDecoder {
 
   // ---- output window (same scheme as the generic kernel) --------------------------------------------------
   __device__ __forceinline__ uint32_t opos() const { return dict_base + len; }
-  __device__ __forceinline__ uint32_t fetch_out(uint32_t pos) { return readfirst(buf_load_u8(out_rsrc, pos)); }
+  __device__ __forceinline__ void finish_pending() {
+    if (pend_n != 0) {
+      buf_store_u8(out_rsrc, threadIdx.x < pend_n ? pend_pos + threadIdx.x : kOob, pend_val);
+      prev = readlane(pend_val, pend_n - 1u);
+      mb = readlane(pend_val, pend_n);
+      pend_n = 0;
+    }
+  }
+  __device__ __forceinline__ uint32_t fetch_out(uint32_t pos) {
+    finish_pending();
+    return readfirst(buf_load_u8(out_rsrc, pos));
+  }
   __device__ __forceinline__ void limit_error() {
     if (lim_is_mem)
       fail(MILZMA_ST_MEMLIMIT, out_lim);
@@ -334,6 +352,17 @@ struct FastDecoder {
     const uint32_t src = pos - dist;
     const bool periodic = dist <= n;
     const float rcp = periodic ? __builtin_amdgcn_rcpf(float(dist)) : 0.0f;
+    finish_pending();  // its store must precede this match's loads (the source may overlap it)
+    if (__builtin_expect(n < kWave && !clipped, 1)) {
+      // one chunk: issue the load now, store later (finish_pending)
+      const uint32_t i = threadIdx.x;
+      const uint32_t j = periodic ? small_mod(i, dist, rcp) : i;
+      pend_val = buf_load_u8(out_rsrc, i <= n ? src + j : kOob);
+      pend_pos = pos;
+      pend_n = n;
+      len += mlen;
+      return true;
+    }
     for (uint32_t i0 = 0; i0 <= n; i0 += kWave) {
       pin_scalars();
       const uint32_t i = i0 + threadIdx.x;
@@ -372,6 +401,7 @@ struct FastDecoder {
   }
 
   __device__ __forceinline__ bool decode_literal(uint32_t* byte_out) {
+    finish_pending();
     if (__builtin_expect(prev == kNoByte, 0)) prev = len == 0 ? 0 : fetch_out(opos() - 1);
     const uint32_t row = literal_row();
     const bool matched = state >= 7;
@@ -506,7 +536,7 @@ struct FastDecoder {
         break;
       }
       slide();
-      if (state >= 7 && prev != kNoByte) prefetch_matched_row(literal_row());  // a literal here would be a matched one
+      if (state >= 7 && pend_n == 0 && prev != kNoByte) prefetch_matched_row(literal_row());  // a literal here would be a matched one
       const uint32_t pos_state = len & pb_mask;
       if (!bit(m_ismatch, state * 4u + pos_state, 0)) {
         uint32_t byte;
@@ -604,6 +634,9 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   d.dict_base = 0;
   d.len = 0;
   d.prev = 0;
+  d.pend_n = 0;
+  d.pend_pos = 0;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(d.pend_val));
   d.mb = kNoByte;
   d.range = 0;
   d.set_code(0);
@@ -664,6 +697,7 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
         }
         uint32_t n = d.header_byte() << 8;
         n = (n | d.header_byte()) + 1;
+        d.finish_pending();
         if (status == 1) {
           d.dict_base += d.len;
           d.len = 0;
@@ -719,6 +753,7 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
       uint32_t packed = d.header_byte() << 8;
       packed = (packed | d.header_byte()) + 1;
       if (reset == 3) {
+        d.finish_pending();
         d.dict_base += d.len;
         d.len = 0;
         d.prev = d.mb = kNoByte;
@@ -776,6 +811,7 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
     d.rem += rem_after;
     if (!ok) break;
   }
+  d.finish_pending();
   const uint64_t total = uint64_t(d.dict_base) + d.len;
   uint64_t flushed = total;
   if (!ok) flushed = raw ? (total / d.dict_size) * d.dict_size : d.dict_base;
