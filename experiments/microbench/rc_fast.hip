@@ -235,9 +235,31 @@ __global__ __launch_bounds__(64) void k_h(const uint32_t* in, uint32_t* out, int
   uint32_t t0 = 0x400u, t1 = t0, t2 = t0, t3 = t0;
   uint32_t acc = 0;
   for (int s = 0; s < nsym; s++) {
-#define TREEH(T) { uint32_t sym = 1; _Pragma("unroll") for (int d = 0; d < 6; d++) bitH<UPD>(rc, T, sym, sym); acc += sym; }
-    TREEH(t0) TREEH(t1) TREEH(t2) TREEH(t3)
+#define TREEH0(T) { uint32_t sym = 1; _Pragma("unroll") for (int d = 0; d < 6; d++) bitH<UPD>(rc, T, sym, sym); acc += sym; }
+    TREEH0(t0) TREEH0(t1) TREEH0(t2) TREEH0(t3)
     if (rc.off >= 192) { rc.off -= 192; rc.win = in[(s * 64 + blockIdx.x + lane) & 0xffff]; }
+  }
+  if (lane == 0) { out[blockIdx.x * 4] = acc; out[blockIdx.x * 4 + 1] = rc.range ^ __builtin_amdgcn_readfirstlane(rc.code); out[blockIdx.x * 4 + 2] = rc.eof; }
+  if (nsym < 0) out[lane] = t0 + t1 + t2 + t3;
+}
+
+#define TREEH(T) { uint32_t sym = 1; _Pragma("unroll") for (int d = 0; d < 6; d++) bitH<0>(rc, T, sym, sym); acc += sym; }
+template <int UNR>
+__global__ __launch_bounds__(64) void k_h_big(const uint32_t* in, uint32_t* out, int nsym) {
+  const uint32_t lane = threadIdx.x;
+  RCH rc;
+  rc.win = in[(blockIdx.x * 64 + lane) & 0xffff];
+  rc.range = 0xffffffffu;
+  rc.code = in[blockIdx.x & 0xffff] >> 1;
+  rc.off = 0; rc.rem = 1u << 30; rc.eof = 0;
+  uint32_t t0 = 0x400u, t1 = t0, t2 = t0, t3 = t0;
+  uint32_t acc = 0;
+  for (int s = 0; s < nsym; s += UNR) {
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      TREEH(t0) TREEH(t1) TREEH(t2) TREEH(t3)
+      if (rc.off >= 192) { rc.off -= 192; rc.win = in[(s * 64 + blockIdx.x + lane) & 0xffff]; }
+    }
   }
   if (lane == 0) { out[blockIdx.x * 4] = acc; out[blockIdx.x * 4 + 1] = rc.range ^ __builtin_amdgcn_readfirstlane(rc.code); out[blockIdx.x * 4 + 2] = rc.eof; }
   if (nsym < 0) out[lane] = t0 + t1 + t2 + t3;
@@ -271,13 +293,16 @@ int main() {
   CHECK(hipMalloc(&d_in, h.size() * 4)); CHECK(hipMalloc(&d_out, 65536 * 4 * 4));
   CHECK(hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   const int nsym = 4000;
-  int wave_counts[] = {256, 1024, 2048, 4096, 8192};
+  int wave_counts[] = {256, 4096};
   for (int w : wave_counts) {
     run("F", k_fast<0>, w, nsym, d_in, d_out);
     run("G", k_fast<1>, w, nsym, d_in, d_out);
     run("P", k_fast<2>, w, nsym, d_in, d_out);
     run("H0", k_h<0>, w, nsym, d_in, d_out);
     run("H1", k_h<1>, w, nsym, d_in, d_out);
+    run("Hx4", k_h_big<4>, w, nsym, d_in, d_out);
+    run("Hx16", k_h_big<16>, w, nsym, d_in, d_out);
+    run("Hx32", k_h_big<32>, w, nsym, d_in, d_out);
   }
   return 0;
 }

@@ -25,7 +25,7 @@ import sys
 from . import workloads  # noqa: F401  (synthetic stream generator, host-only)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmilzma.so")
+_LIB_PATH = os.environ.get("MILZMA_LIB") or os.path.join(_HERE, "libmilzma.so")
 
 # ---- error kinds / statuses (include/milzma.h) ---------------------------------------------
 OK, IO_ERROR, HEADER_TOO_SHORT, LZMA_ERROR, XZ_ERROR, INFRA_ERROR = range(6)

@@ -31,6 +31,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kNoByte = 0xFFFFFFFFu;
 
+// Cycle attribution for tuning (make prof): per-unit s_memtime deltas, reported through
+// milzma_result.err_a / err_b of successful units.  Not part of the product build.
+#ifdef MILZMA_PROFILE
+#define MILZMA_PROF_NOW() uint32_t(__builtin_amdgcn_s_memtime())
+#define MILZMA_PROF_ADD(acc, t0) (acc) += MILZMA_PROF_NOW() - (t0)
+#else
+#define MILZMA_PROF_NOW() 0u
+#define MILZMA_PROF_ADD(acc, t0) (void)(t0)
+#endif
+
 struct FastDecoder {
   // ---- input: 256-byte window (dword per lane) that always has >= 64 bytes ahead of `off` at the
   //      start of a symbol, so normalisation never has to refill mid-symbol ---------------------
@@ -80,6 +90,7 @@ struct FastDecoder {
   uint32_t pend_pos;  // where they go
   uint32_t pend_val;  // VGPR
   uint32_t status;
+  uint32_t prof_lit, prof_copy, prof_match, prof_nlit;  // MILZMA_PROFILE only
   milzma_result* res;  // error arguments go straight to the result record (keeps them out of SGPRs)
 
   __device__ __forceinline__ void fail(uint32_t st, uint64_t a = 0, uint64_t b = 0) {
@@ -95,8 +106,14 @@ struct FastDecoder {
 
   // ---- reader ----------------------------------------------------------------------------------
   __device__ __forceinline__ uint32_t load_window(uint32_t wpos) const {
-    // lane's dword of the window starting at virtual position wpos (0 beyond the resource's end)
-    return buf_load_u32(in_rsrc, wpos + threadIdx.x * 4u);
+    // lane's dword of the window starting at virtual position wpos (0 beyond the resource's end).
+    // The value is passed through a v_mov so that the load is waited for HERE (once per 192 input
+    // bytes): a window register that is still "in flight" across the symbol loop makes hipcc put an
+    // s_waitcnt vmcnt(0) at the top of every iteration, which also waits for every outstanding
+    // output store (rocprof: 28 % of wave time in s_waitcnt).
+    uint32_t w = buf_load_u32(in_rsrc, wpos + threadIdx.x * 4u);
+    asm volatile("v_mov_b32 %0, %0" : "+v"(w));
+    return w;
   }
   __device__ __forceinline__ uint32_t vpos() const { return wbase + off; }
   __device__ __forceinline__ void seek(uint32_t v) {
@@ -352,6 +369,7 @@ struct FastDecoder {
     const uint32_t src = pos - dist;
     const bool periodic = dist <= n;
     const float rcp = periodic ? __builtin_amdgcn_rcpf(float(dist)) : 0.0f;
+    const uint32_t t_copy = MILZMA_PROF_NOW();
     finish_pending();  // its store must precede this match's loads (the source may overlap it)
     if (__builtin_expect(n < kWave && !clipped, 1)) {
       // one chunk: issue the load now, store later (finish_pending)
@@ -361,6 +379,7 @@ struct FastDecoder {
       pend_pos = pos;
       pend_n = n;
       len += mlen;
+      MILZMA_PROF_ADD(prof_copy, t_copy);
       return true;
     }
     for (uint32_t i0 = 0; i0 <= n; i0 += kWave) {
@@ -401,7 +420,9 @@ struct FastDecoder {
   }
 
   __device__ __forceinline__ bool decode_literal(uint32_t* byte_out) {
+    const uint32_t t_fin = MILZMA_PROF_NOW();
     finish_pending();
+    MILZMA_PROF_ADD(prof_match, t_fin);
     if (__builtin_expect(prev == kNoByte, 0)) prev = len == 0 ? 0 : fetch_out(opos() - 1);
     const uint32_t row = literal_row();
     const bool matched = state >= 7;
@@ -541,7 +562,9 @@ struct FastDecoder {
       if (!bit(m_ismatch, state * 4u + pos_state, 0)) {
         uint32_t byte;
         if (__builtin_expect(eof, 0)) return fail(MILZMA_ST_INPUT_EOF), false;
+        const uint32_t t_lit = MILZMA_PROF_NOW();
         if (!decode_literal(&byte)) return false;
+        MILZMA_PROF_ADD(prof_lit, t_lit);
         if (__builtin_expect(eof, 0)) return fail(MILZMA_ST_INPUT_EOF), false;
         if (!append_literal(byte)) return false;
         state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);
@@ -623,6 +646,8 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   __shared__ uint32_t lds_matched[8 * 64 * 4];
   u32x16 lit_plain;
   u32x4 posslot;
+  const uint32_t t_kernel0 = MILZMA_PROF_NOW();
+  (void)t_kernel0;
   FastDecoder d;
   d.lit_plain = &lit_plain;
   d.lit_matched = lds_matched;
@@ -630,6 +655,7 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   d.out_rsrc = make_rsrc(out_base + u.out_off, uint32_t(u.out_cap));
   d.status = MILZMA_ST_OK;
   d.res = res;
+  d.prof_lit = d.prof_copy = d.prof_match = d.prof_nlit = 0;
   d.eof = 0;
   d.dict_base = 0;
   d.len = 0;
@@ -822,8 +848,13 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   res->out_flushed = flushed;
   res->in_consumed = d.vpos() - a0;
   if (d.status == MILZMA_ST_OK) {
+#ifdef MILZMA_PROFILE
+    res->err_a = (uint64_t(d.prof_lit) << 32) | d.prof_copy;
+    res->err_b = (uint64_t(d.prof_match) << 32) | (MILZMA_PROF_NOW() - t_kernel0);
+#else
     res->err_a = 0;
     res->err_b = 0;
+#endif
   }
 }
 
