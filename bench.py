@@ -234,6 +234,16 @@ def main():
     step_s = elapsed / args.steps
     value = total_out / step_s / 1e9
     k_ms = sum(kernel_ms) / len(kernel_ms)
+    # HBM-side traffic cannot be read from inside the process: it comes from a separate
+    # `rocprofv3 --pmc FETCH_SIZE` pass of this same command, summarised under profiles/.
+    traffic, traffic_note = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_fast_pmc_summary.json")
+    if os.path.exists(pmc_path) and args.kind == "text" and n == 4096 and args.size == 1 << 20 and args.dict == 1 << 16:
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic = pmc["derived"]["fetch_bytes_per_launch"]
+        traffic_note = ("L2->fabric read bytes per launch (FETCH_SIZE, rocprofv3 --pmc pass recorded in "
+                        "profiles/r01_fast_pmc_summary.json; WRITE_SIZE pass not available)")
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
@@ -263,7 +273,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                 "kernel": "decode kernel(s) of one milzma_decode_units call", "kernel_ms": round(k_ms, 3),
                 "launches_per_step": launches, "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "serial range-decoder dependency chain bounds this path, not HBM (DESIGN.md)",
