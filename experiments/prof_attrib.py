@@ -35,8 +35,9 @@ for _ in range(2):
     res, ms, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
 lit = sum(r.err_a >> 32 for r in res) / n
 copy = sum(r.err_a & 0xFFFFFFFF for r in res) / n
-stall = sum(r.err_b >> 32 for r in res) / n
-total = sum(r.err_b & 0xFFFFFFFF for r in res) / n
-print("kernel %.1f ms; per unit (s_memtime ticks, 32-bit wrap possible): total %.0f literal %.0f (%.1f%%) copy-issue %.0f (%.1f%%) "
-      "pending-finish-before-literal %.0f (%.1f%%)" % (ms, total, lit, 100 * lit / total, copy, 100 * copy / total, stall,
-                                                        100 * stall / total))
+dist = sum(r.err_b >> 32 for r in res) / n
+total = 16 * sum(r.err_b & 0xFFFFFFFF for r in res) / n
+lend = sum(r.out_flushed >> 32 for r in res) / n
+print("kernel %.1f ms; per unit s_memtime ticks: total %.0f | literal decode %.0f (%.1f%%) | new-match len decode %.0f (%.1f%%) | "
+      "distance decode %.0f (%.1f%%) | copy issue %.0f (%.1f%%)" % (ms, total, lit, 100 * lit / total, lend, 100 * lend / total,
+                                                                    dist, 100 * dist / total, copy, 100 * copy / total))

@@ -420,9 +420,7 @@ struct FastDecoder {
   }
 
   __device__ __forceinline__ bool decode_literal(uint32_t* byte_out) {
-    const uint32_t t_fin = MILZMA_PROF_NOW();
     finish_pending();
-    MILZMA_PROF_ADD(prof_match, t_fin);
     if (__builtin_expect(prev == kNoByte, 0)) prev = len == 0 ? 0 : fetch_out(opos() - 1);
     const uint32_t row = literal_row();
     const bool matched = state >= 7;
@@ -602,9 +600,13 @@ struct FastDecoder {
         rep3 = rep2;
         rep2 = rep1;
         rep1 = rep0;
+        const uint32_t t_len = MILZMA_PROF_NOW();
         mlen = len_decode(0, pos_state, m_len_lm, m_len_h0, m_len_h1, m_len_h2, m_len_h3);
+        MILZMA_PROF_ADD(prof_nlit, t_len);
         state = state < 7 ? 7 : 10;
+        const uint32_t t_dist = MILZMA_PROF_NOW();
         rep0 = decode_distance(mlen);
+        MILZMA_PROF_ADD(prof_match, t_dist);
         if (__builtin_expect(eof, 0)) return fail(MILZMA_ST_INPUT_EOF), false;
         if (__builtin_expect(rep0 == 0xFFFFFFFFu, 0)) {
           if (rem == 0 && readfirst(code) == 0) return true;
@@ -850,7 +852,8 @@ __global__ __launch_bounds__(64, 4) void decode_fast_kernel(const milzma_unit* _
   if (d.status == MILZMA_ST_OK) {
 #ifdef MILZMA_PROFILE
     res->err_a = (uint64_t(d.prof_lit) << 32) | d.prof_copy;
-    res->err_b = (uint64_t(d.prof_match) << 32) | (MILZMA_PROF_NOW() - t_kernel0);
+    res->err_b = (uint64_t(d.prof_match) << 32) | ((MILZMA_PROF_NOW() - t_kernel0) >> 4);
+    res->out_flushed = (uint64_t(d.prof_nlit) << 32) | uint32_t(res->out_flushed);
 #else
     res->err_a = 0;
     res->err_b = 0;
