@@ -45,7 +45,10 @@ struct milzma_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   uint32_t last_launches = 0;
-  bool use_fast = true;  // MILZMA_KERNEL=generic turns the lane-resident-model kernel off (A/B runs, tests)
+  // MILZMA_KERNEL (A/B runs, tests): "generic" turns the lane-resident-model kernels off, "fast" picks the
+  // one whose symbol loop is C++, "asm" (default) the one whose symbol loop is hand-scheduled asm.
+  bool use_fast = true;
+  int fast_variant = 1;
 };
 
 namespace {
@@ -101,7 +104,10 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   }
   auto* ctx = new milzma_ctx();
   ctx->device = device;
-  if (const char* k = getenv("MILZMA_KERNEL")) ctx->use_fast = strcmp(k, "generic") != 0;
+  if (const char* k = getenv("MILZMA_KERNEL")) {
+    ctx->use_fast = strcmp(k, "generic") != 0;
+    ctx->fast_variant = strcmp(k, "fast") == 0 ? 0 : 1;
+  }
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
       !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
     delete ctx;
@@ -172,7 +178,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
-    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream)
+    const hipError_t le = cls == kFast ? launch_fast(ctx->fast_variant, d_units, d_order + i, m, d_in, d_out, d_results, stream)
                                        : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;

@@ -25,7 +25,8 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
                           hipStream_t stream);
 
 // The lane-resident-model kernel (pb <= 2, lc + lp <= 3): no LDS, 16 waves per CU.
-hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in,
-                       uint8_t* d_out, milzma_result* d_results, hipStream_t stream);
+// variant 0: decode_fast_kernel (symbol loop in C++), 1: decode_fast_asm_kernel (symbol loop in gfx950 asm)
+hipError_t launch_fast(int variant, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
+                       const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, hipStream_t stream);
 
 }  // namespace milzma

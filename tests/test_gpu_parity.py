@@ -27,10 +27,11 @@ def gold(name):
         return f.read()
 
 
-@pytest.fixture(scope="module", params=["fast", "generic"])
+@pytest.fixture(scope="module", params=["asm", "fast", "generic"])
 def ctx(request):
-    """Every test runs twice: with the lane-resident-model kernel enabled (units outside its class
-    still fall through to the generic kernel) and with the generic kernel only."""
+    """Every test runs three times: with the lane-resident-model kernel whose symbol loop is asm (the
+    default), with the one whose symbol loop is C++ (units outside their class still fall through to
+    the generic kernel) and with the generic kernel only."""
     os.environ["MILZMA_KERNEL"] = request.param
     c = M.Context(0)
     yield c
