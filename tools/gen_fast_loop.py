@@ -38,10 +38,11 @@ import re
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90")
+         c2017="s90", c2048="s91")
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
-         vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98")
+         vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
+         VLANE192="v101")
 MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
@@ -51,6 +52,7 @@ CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
 PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
+K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
 
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
@@ -58,8 +60,8 @@ OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
                "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val"]
-OPS_IN_S = ["out_lim", "target", "known", "dict_size", "dict_base", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
-            "out_rsrc", "ldsbase"]
+OPS_IN_S = ["out_lim", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc", "out_rsrc",
+            "ldsbase"]
 OPS_IN_V = ["v_lane"]
 
 
@@ -136,12 +138,12 @@ class Gen:
             self.e("s_call_b64 " + RET + ", " + self.L("refill"))
             self.e("s_branch " + self.L(ret))
 
-    def core(self, T, ln, half=None):
+    def core(self, T, ln, half=None, cmp_lane=None):
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
         0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
         self.e("v_readlane_b32 {sp}, {T}, {ln}", T=T, ln=ln)
-        self.e("v_cmp_eq_u32 vcc, {ln}, {v_lane}", ln=ln)
+        self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
         if half == 0:
             self.e("s_and_b32 {sp}, {sp}, 0xffff")
             self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
@@ -162,25 +164,48 @@ class Gen:
         self.e("v_add_u32 {vt}, {T}, {vt}", T=T)        # low half: the sign extension of a negative delta cancels
         self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)  # against the carry out of the (non-negative) low half
 
+    # p += (K - p) >> 5 with K = 2048 for a 0 bit and 31 for a 1 bit (the arithmetic shift makes the second
+    # -(p >> 5)); for an unpacked probability this is (31 * p + K) >> 5: one v_mad and one shift.
     def post_known(self, T, bit0, half=None):
-        """probability update when the bit value is known from the branch taken: p += (K - p) >> 5 with
-        K = 2048 for a 0 bit, 31 for a 1 bit"""
-        src = T if half is None else R("vx")
-        self.e("v_sub_u32 {vt}, %s, {src}" % ("0x800" if bit0 else "31"), src=src)
+        """probability update when the bit value is known from the branch taken"""
+        if half is None:
+            self.e("v_mad_u32_u24 {vt}, {T}, 31, %s" % ("{c2048}" if bit0 else "31"), T=T)
+            self.e("v_lshrrev_b32 {vt}, 5, {vt}")
+            self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
+            return
+        self.e("v_sub_u32 {vt}, %s, {vx}" % ("0x800" if bit0 else "31"))
         self._apply(T, half)
+
+    def pre_sym(self):
+        """scalar part of the update of a tree decision; call while SCC = (bit == 0)"""
+        if not K_ON_VALU:
+            self.e("s_cselect_b32 {sk}, {c2048}, 31")
 
     def post_sym(self, T, half=None):
-        """probability update from the symbol's new low bit (1 = the bit was 0): K = 31 + 2017 * low bit"""
-        src = T if half is None else R("vx")
-        self.e("v_sub_u32 {vx}, 31, {src}", src=src)
-        self.e("v_and_b32 {vt}, 1, {sym}")
-        self.e("v_mad_u32_u24 {vt}, {vt}, {c2017}, {vx}")
+        """probability update of a tree decision (the symbol's new low bit is 1 if the bit was 0)"""
+        if half is None:
+            if K_ON_VALU:
+                self.e("v_and_b32 {vt}, 1, {sym}")
+                self.e("v_mad_u32_u24 {vt}, {vt}, {c2017}, 31")       # K = 31 + 2017 * low bit
+                self.e("v_mad_u32_u24 {vt}, {T}, 31, {vt}", T=T)
+            else:
+                self.e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
+            self.e("v_lshrrev_b32 {vt}, 5, {vt}")
+            self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
+            return
+        if K_ON_VALU:
+            self.e("v_sub_u32 {vx}, 31, {vx}")
+            self.e("v_and_b32 {vt}, 1, {sym}")
+            self.e("v_mad_u32_u24 {vt}, {vt}, {c2017}, {vx}")
+        else:
+            self.e("v_sub_u32 {vt}, {sk}, {vx}")
         self._apply(T, half)
 
-    def bit(self, T, ln, half=None, first=False):
+    def bit(self, T, ln, half=None, first=False, cmp_lane=None):
         """one tree decision: sym = 2 * sym + (bit == 0), then normalise.  first: sym was 1 (not
         materialised), ln is the constant lane of the root."""
-        self.core(T, ln, half)
+        self.core(T, ln, half, cmp_lane)
+        self.pre_sym()
         if first:
             self.e("s_cselect_b32 {sym}, 3, 2")
         else:
@@ -253,18 +278,16 @@ class Gen:
         self.bit(R(p + "_h0"), "1", first=True)
         for _ in range(5):
             self.bit(R(p + "_h0"), R("sym"))
-        self.e("s_and_b32 {ln}, {sym}, 63")
-        self.bit(R(p + "_h1"), R("ln"))
-        self.e("s_and_b32 {ln}, {sym}, 63")
+        self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
         self.e("s_bitcmp1_b32 {sym}, 6")
         self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
-        self.bit(R(p + "_h2"), R("ln"))
+        self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
         self.lab(w + "_hdone")
         self.e("s_xor_b32 {mlen}, {sym}, 0x1ff")
         self.e("s_add_u32 {mlen}, {mlen}, 16")
         self.e("s_branch " + self.L(done))
         self.lab(w + "_h3")
-        self.bit(R(p + "_h3"), R("ln"))
+        self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
         self.e("s_branch " + self.L(w + "_hdone"))
 
     def reverse_tree_based(self, T, base_reg, nbits, out):
@@ -281,6 +304,73 @@ class Gen:
         self.e("s_brev_b32 {o}, {o}", o=out)
 
     # ---- the loop ------------------------------------------------------------------------------------------
+    def prev_fetch(self, ret):
+        e = self.e
+        e("s_mov_b32 {pend_n}, 0")
+        e("s_mov_b32 {prev}, 0")
+        e("s_cmp_eq_u32 {len}, 0")
+        e("s_cbranch_scc1 " + self.L(ret))
+        e("s_add_u32 {t0}, {len}, -1")
+        e("v_mov_b32 {VT0}, {t0}")
+        e("buffer_load_ubyte {VT0}, {VT0}, {out_rsrc}, 0 offen")
+        e("s_waitcnt vmcnt(0)")
+        e("v_readfirstlane_b32 {prev}, {VT0}")
+        e("s_branch " + self.L(ret))
+
+    def row_swap_stub(self, name, ret):
+        """out of line: park the cached literal row, unpack the new one (cur_row -> row)"""
+        e = self.e
+        with self.in_cold():
+            self.lab(name)
+            e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
+            e("v_lshl_or_b32 {VT1}, {u3}, 16, {u2}")
+            e("s_lshl_b32 {t0}, {cur_row}, 1")
+            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
+            e("v_mov_b32 " + LIT0 + ", {VT0}")
+            e("v_mov_b32 " + LIT1 + ", {VT1}")
+            e("s_set_gpr_idx_off")
+            e("s_lshl_b32 {t0}, {row}, 1")
+            e("s_set_gpr_idx_on {t0}, gpr_idx(SRC0)")
+            e("v_mov_b32 {VT0}, " + LIT0)
+            e("v_mov_b32 {VT1}, " + LIT1)
+            e("s_set_gpr_idx_off")
+            e("v_and_b32 {u0}, 0xffff, {VT0}")
+            e("v_lshrrev_b32 {u1}, 16, {VT0}")
+            e("v_and_b32 {u2}, 0xffff, {VT1}")
+            e("v_lshrrev_b32 {u3}, 16, {VT1}")
+            e("s_mov_b32 {cur_row}, {row}")
+            e("s_branch " + self.L(ret))
+
+    def symbol_top(self, tag):
+        """top of a symbol (lzma.rs:435-459) up to the is_match decision; falls through for a literal"""
+        e, lab, L = self.e, self.lab, self.L
+        lab("top" + tag)
+        e("s_cmp_ge_u32 {len}, {target}")
+        e("s_cbranch_scc1 " + L("Xdone_size"))
+        e("s_cmp_eq_u32 {off}, {lim}")                   # reader at EOF: the stream may be finished
+        e("s_cbranch_scc1 " + L("Ofin_check" + tag))
+        lab("top2" + tag)
+        e("s_and_b32 {ps}, {len}, {pbmask}")
+        e("s_lshl2_add_u32 {ln}, {state}, {ps}")
+        self.decide(R("m_ismatch"), R("ln"), "match")
+        with self.in_cold():
+            lab("Ofin_check" + tag)                           # unknown size: finished when the reader is at EOF
+            e("s_or_b32 {t0}, {code}, {known}")               # and code == 0 (is_finished_ok, rangecoder.rs:48-50)
+            e("s_cbranch_scc0 " + L("Xdone_fin"))
+            e("s_branch " + L("top2" + tag))
+
+    def literal_row(self, tag):
+        e, L = self.e, self.L
+        e("s_and_b32 {t0}, {len}, {lpmask}")
+        e("s_lshl_b32 {t0}, {t0}, {lc}")
+        e("s_lshr_b32 {t1}, {prev}, {lc8}")
+        e("s_add_u32 {row}, {t0}, {t1}")
+        e("s_cmp_lg_u32 {row}, {cur_row}")
+        e("s_cbranch_scc1 " + L("Orow_swap" + tag))
+        self.lab("lit_r" + tag)
+        self.row_swap_stub("Orow_swap" + tag, "lit_r" + tag)
+
+    # ---- the loop ------------------------------------------------------------------------------------------
     def build(self):
         e, lab, L = self.e, self.lab, self.L
         # prologue: per-lane constants
@@ -288,65 +378,61 @@ class Gen:
         e("v_cmp_eq_u32 vcc, 0, {v_lane}")
         e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
         e("v_mov_b32 {VKTOP}, 0x1000000")
+        e("v_add_u32 {VLANE64}, 64, {v_lane}")
+        e("v_add_u32 {VLANE128}, 0x80, {v_lane}")
+        e("v_add_u32 {VLANE192}, 0xc0, {v_lane}")
         e("s_movk_i32 {c2017}, 2017")
-
-        # ================= top of a symbol (lzma.rs:435-459) =================
-        lab("top")
-        e("s_cmp_ge_u32 {len}, {target}")
-        e("s_cbranch_scc1 " + L("Xdone_size"))
-        e("s_cmp_eq_u32 {off}, {lim}")                   # reader at EOF: the stream may be finished
-        e("s_cbranch_scc1 " + L("Ofin_check"))
-        lab("top2")
-        e("s_and_b32 {ps}, {len}, {pbmask}")
-        e("s_lshl2_add_u32 {ln}, {state}, {ps}")
-        self.decide(R("m_ismatch"), R("ln"), "match")
-
-        # ================= literal (lzma.rs:526-561) =================
-        e("s_cmp_lg_u32 {pend_n}, 0")
-        e("s_cbranch_scc1 " + L("Opend_lit"))
-        lab("lit_p")
-        e("s_and_b32 {t0}, {len}, {lpmask}")
-        e("s_lshl_b32 {t0}, {t0}, {lc}")
-        e("s_lshr_b32 {t1}, {prev}, {lc8}")
-        e("s_add_u32 {row}, {t0}, {t1}")
-        e("s_cmp_lg_u32 {row}, {cur_row}")
-        e("s_cbranch_scc1 " + L("Orow_swap"))
-        lab("lit_r")
+        e("s_movk_i32 {c2048}, 0x800")
+        # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
+        # prev at hand: a literal here is a plain one) and "M" after a match (state >= 7: a literal here is
+        # a matched one and first completes the pending match).
         e("s_cmpk_ge_u32 {state}, 7")
-        e("s_cbranch_scc1 " + L("lit_matched"))
+        e("s_cbranch_scc1 " + L("topM"))
+        e("s_cmp_lg_u32 {pend_n}, 0")                    # entered from C++ with prev unknown
+        e("s_cbranch_scc1 " + L("Oentry_fix"))
+
+        # ================= after a literal =================
+        self.symbol_top("L")
+        # ---- plain literal (lzma.rs:526-561)
+        self.literal_row("L")
         e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
         e("s_max_i32 {state}, {state}, 0")
         self.bit(R("u0"), "1", first=True)
         for i in range(1, 6):       # nodes 1..63 -> u0
             lab("plain%d" % i)
             self.bit(R("u0"), R("sym"))
-        lab("plain6")               # nodes 64..127 -> u1
-        e("s_and_b32 {ln}, {sym}, 63")
-        self.bit(R("u1"), R("ln"))
+        lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
+        self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
         lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
-        e("s_and_b32 {ln}, {sym}, 63")
         e("s_bitcmp1_b32 {sym}, 6")
         e("s_cbranch_scc1 " + L("plain7_hi"))
-        self.bit(R("u2"), R("ln"))
+        self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
         lab("lit_done")
         e("s_xor_b32 {prev}, {sym}, 0x1ff")             # (0x100 | inverted path) -> byte
-        e("s_add_u32 {t0}, {dict_base}, {len}")
-        e("s_cmp_ge_u32 {t0}, {out_lim}")
+        e("s_cmp_ge_u32 {len}, {out_lim}")
         e("s_cbranch_scc1 " + L("Xlimit"))
         e("v_mov_b32 {VT0}, {prev}")
-        e("v_or_b32 {VT1}, {t0}, {VOOB}")
+        e("v_or_b32 {VT1}, {len}, {VOOB}")
         e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen")
         e("s_add_u32 {len}, {len}, 1")
-        e("s_branch " + L("top"))
+        e("s_branch " + L("topL"))
         with self.in_cold():
             lab("plain7_hi")
-            self.bit(R("u3"), R("ln"))
+            self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
             e("s_branch " + L("lit_done"))
 
+        # ================= after a match =================
+        self.symbol_top("M")
         # ---- matched literal: probs[((1 + match_bit) << 8) + sym] (lzma.rs:541-555).  The row's two
         #      matched sub-tables are in LDS, dword k of a lane = nodes 64k..64k+63, low half for
         #      match_bit 0 and high half for match_bit 1.
-        lab("lit_matched")
+        e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)   # prev / mb unknown (or, entering from C++, nothing pending)
+        e("s_cbranch_scc1 " + L("Oprev_fetchM"))
+        e("s_cmp_eq_u32 {pend_n}, 0")
+        e("s_cbranch_scc1 " + L("lit_pM"))
+        self.finish_pending()
+        lab("lit_pM")
+        self.literal_row("M")
         e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
         e("s_cselect_b32 {t1}, 3, 6")
         e("s_sub_u32 {state}, {state}, {t1}")
@@ -366,14 +452,13 @@ class Gen:
             lab("lm%d" % i)
             first = i == 0
             T = V["M0"] if i < 6 else V["M1"]
-            lnreg = "1" if first else (R("sym") if i < 6 else R("ln"))
+            lnreg = "1" if first else R("sym")
+            cl = V["VLANE64"] if i == 6 else None
             acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
-            if i == 6:
-                e("s_and_b32 {ln}, {sym}, 63")
             e("s_bitcmp1_b32 {mb}, %d" % (7 - i))           # the match byte's next bit picks the sub-table
             e("s_cbranch_scc1 " + L("lm%d_m1" % i))
             mis0, mis1 = self.new("MIS"), self.new("MIS")
-            self.core(T, lnreg, half=0)                       # match bit 0: still matched if the bit is 0 (SCC = 1)
+            self.core(T, lnreg, half=0, cmp_lane=cl)          # match bit 0: still matched if the bit is 0 (SCC = 1)
             e("s_cbranch_scc0 " + L(mis0))
             e(acc)
             self.post_known(T, True, half=0)
@@ -385,7 +470,7 @@ class Gen:
                 e("ds_write_b128 {VA}, " + MROW)
                 self.norm(to="plain%d" % (i + 1))
                 lab("lm%d_m1" % i)
-                self.core(T, lnreg, half=1)                   # match bit 1: still matched if the bit is 1 (SCC = 0)
+                self.core(T, lnreg, half=1, cmp_lane=cl)      # match bit 1: still matched if the bit is 1 (SCC = 0)
                 e("s_cbranch_scc1 " + L(mis1))
                 e(acc)
                 self.post_known(T, False, half=1)
@@ -396,28 +481,33 @@ class Gen:
                 e("ds_write_b128 {VA}, " + MROW)
                 self.norm(to="plain%d" % (i + 1))
         lab("lm7")                   # last level: nodes 128..191 in M2, 192..255 in M3; nothing follows a mismatch
-        e("s_and_b32 {ln}, {sym}, 63")
         e("s_bitcmp1_b32 {sym}, 6")
         e("s_cbranch_scc1 " + L("lm7_hi"))
         e("s_bitcmp1_b32 {mb}, 0")
         e("s_cbranch_scc1 " + L("lm7_lo_m1"))
-        self.core(V["M2"], R("ln"), half=0)
+        self.core(V["M2"], R("sym"), half=0, cmp_lane=V["VLANE128"])
+        self.pre_sym()
         e("s_addc_u32 {sym}, {sym}, {sym}")
         self.post_sym(V["M2"], half=0)
         lab("lm_full")
         e("ds_write_b128 {VA}, " + MROW)
         self.norm(to="lit_done")
         with self.in_cold():
-            for name, T, half, pre in [("lm7_lo_m1", "M2", 1, None), ("lm7_hi", "M3", 0, "lm7_hi_m1"),
-                                       ("lm7_hi_m1", "M3", 1, None)]:
+            for name, T, half, pre, cl in [("lm7_lo_m1", "M2", 1, None, "VLANE128"), ("lm7_hi", "M3", 0, "lm7_hi_m1", "VLANE192"),
+                                           ("lm7_hi_m1", "M3", 1, None, "VLANE192")]:
                 lab(name)
                 if pre:
                     e("s_bitcmp1_b32 {mb}, 0")
                     e("s_cbranch_scc1 " + L(pre))
-                self.core(V[T], R("ln"), half=half)
+                self.core(V[T], R("sym"), half=half, cmp_lane=V[cl])
+                self.pre_sym()
                 e("s_addc_u32 {sym}, {sym}, {sym}")
                 self.post_sym(V[T], half=half)
                 e("s_branch " + L("lm_full"))
+            lab("Oprev_fetchM")                               # lzb.last_or(0) when the previous byte is not at hand
+            self.prev_fetch("lit_pM")
+            lab("Oentry_fix")
+            self.prev_fetch("topL")
 
         # ================= match (lzma.rs:480-523) =================
         lab("match")
@@ -567,15 +657,14 @@ class Gen:
         e("s_cbranch_scc1 " + L("Xlz_dist_out"))
         e("s_cmpk_ge_u32 {mlen}, 64")
         e("s_cbranch_scc1 " + L("Xlz_slow"))
-        e("s_add_u32 {t1}, {dict_base}, {len}")               # pos
-        e("s_add_u32 {t2}, {t1}, {mlen}")
+        e("s_add_u32 {t2}, {len}, {mlen}")                    # the output resource starts at dict_base: pos = len
         e("s_cbranch_scc1 " + L("Xlz_slow"))
         e("s_cmp_gt_u32 {t2}, {out_lim}")
         e("s_cbranch_scc1 " + L("Xlz_slow"))
         e("s_cmp_lg_u32 {pend_n}, 0")
         e("s_cbranch_scc1 " + L("Opend_copy"))
         lab("cp_a")
-        e("s_sub_u32 {t2}, {t1}, {t0}")                       # src = pos - dist
+        e("s_sub_u32 {t2}, {len}, {t0}")                      # src = pos - dist
         e("s_cmp_le_u32 {t0}, {mlen}")
         e("s_cbranch_scc1 " + L("Operiodic"))
         e("v_add_u32 {VT0}, {t2}, {v_lane}")
@@ -583,18 +672,13 @@ class Gen:
         e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
         e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
         e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
-        e("s_mov_b32 {pend_pos}, {t1}")
+        e("s_mov_b32 {pend_pos}, {len}")
         e("s_mov_b32 {pend_n}, {mlen}")
         e("s_add_u32 {len}, {len}, {mlen}")
-        e("s_branch " + L("top"))
+        e("s_branch " + L("topM"))
 
         # ================= out-of-line helpers =================
         with self.in_cold():
-            lab("Ofin_check")                                 # unknown size: finished when the reader is at EOF
-            e("s_or_b32 {t0}, {code}, {known}")               # and code == 0 (is_finished_ok, rangecoder.rs:48-50)
-            e("s_cbranch_scc0 " + L("Xdone_fin"))
-            e("s_branch " + L("top2"))
-
             lab("Operiodic")                                  # source index = lane % dist (exact: lane < 64)
             e("v_cvt_f32_u32 {VT1}, {t0}")
             e("v_rcp_f32 {VT1}, {VT1}")
@@ -606,24 +690,6 @@ class Gen:
             e("v_sub_u32 {VT2}, {v_lane}, {VT2}")
             e("v_add_u32 {VT0}, {t2}, {VT2}")
             e("s_branch " + L("cp_b"))
-
-            lab("Opend_lit")
-            e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
-            e("s_cbranch_scc1 " + L("Oprev_fetch"))
-            self.finish_pending()
-            e("s_branch " + L("lit_p"))
-            lab("Oprev_fetch")                                # lzb.last_or(0) when the previous byte is not at hand
-            e("s_mov_b32 {pend_n}, 0")
-            e("s_mov_b32 {prev}, 0")
-            e("s_cmp_eq_u32 {len}, 0")
-            e("s_cbranch_scc1 " + L("lit_p"))
-            e("s_add_u32 {t0}, {dict_base}, {len}")
-            e("s_add_u32 {t0}, {t0}, -1")
-            e("v_mov_b32 {VT0}, {t0}")
-            e("buffer_load_ubyte {VT0}, {VT0}, {out_rsrc}, 0 offen")
-            e("s_waitcnt vmcnt(0)")
-            e("v_readfirstlane_b32 {prev}, {VT0}")
-            e("s_branch " + L("lit_p"))
 
             lab("Opend_copy")
             e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
@@ -646,33 +712,12 @@ class Gen:
             e("s_setpc_b64 " + RET)
 
             lab("Omb_fetch")                                  # lzb.last_n(rep0 + 1)
-            e("s_add_u32 {t1}, {dict_base}, {len}")
-            e("s_sub_u32 {t1}, {t1}, {t0}")
+            e("s_sub_u32 {t1}, {len}, {t0}")
             e("v_mov_b32 {VT0}, {t1}")
             e("buffer_load_ubyte {VT0}, {VT0}, {out_rsrc}, 0 offen")
             e("s_waitcnt vmcnt(0)")
             e("v_readfirstlane_b32 {mb}, {VT0}")
             e("s_branch " + L("lm_a"))
-
-            lab("Orow_swap")                                  # park the cached literal row, unpack the new one
-            e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
-            e("v_lshl_or_b32 {VT1}, {u3}, 16, {u2}")
-            e("s_lshl_b32 {t0}, {cur_row}, 1")
-            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
-            e("v_mov_b32 " + LIT0 + ", {VT0}")
-            e("v_mov_b32 " + LIT1 + ", {VT1}")
-            e("s_set_gpr_idx_off")
-            e("s_lshl_b32 {t0}, {row}, 1")
-            e("s_set_gpr_idx_on {t0}, gpr_idx(SRC0)")
-            e("v_mov_b32 {VT0}, " + LIT0)
-            e("v_mov_b32 {VT1}, " + LIT1)
-            e("s_set_gpr_idx_off")
-            e("v_and_b32 {u0}, 0xffff, {VT0}")
-            e("v_lshrrev_b32 {u1}, 16, {VT0}")
-            e("v_and_b32 {u2}, 0xffff, {VT1}")
-            e("v_lshrrev_b32 {u3}, 16, {VT1}")
-            e("s_mov_b32 {cur_row}, {row}")
-            e("s_branch " + L("lit_r"))
 
             for name, code in [("Xdone_size", "DONE_SIZE"), ("Xdone_fin", "DONE_FIN"), ("Xeof", "INPUT_EOF"),
                                ("Xmarker", "MARKER"), ("Xlimit", "LIMIT"), ("Xlz_slow", "LZ_SLOW"),
