@@ -42,7 +42,7 @@ S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78"
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
-         VLANE192="v101")
+         VLANE192="v101", vb="v102")
 MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
@@ -53,6 +53,7 @@ EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, 
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
 PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
 K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
+BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
 
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
@@ -142,16 +143,27 @@ class Gen:
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
         0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
-        self.e("v_readlane_b32 {sp}, {T}, {ln}", T=T, ln=ln)
-        self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
-        if half == 0:
-            self.e("s_and_b32 {sp}, {sp}, 0xffff")
-            self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
-        elif half == 1:
-            self.e("s_lshr_b32 {sp}, {sp}, 16")
-            self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
-        self.e("s_lshr_b32 {sb}, {range}, 11")
-        self.e("s_mul_i32 {sb}, {sb}, {sp}")
+        if BOUND_ON_VALU:
+            # every lane computes the bound of its own probability; the one that is needed is read out
+            self.e("v_lshrrev_b32 {vt}, 11, {range}")
+            if half == 0:
+                self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
+            elif half == 1:
+                self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
+            self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
+            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))  # (also keeps the
+            self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)  # v_readlane one instruction away from vb's producer)
+        else:
+            self.e("v_readlane_b32 {sp}, {T}, {ln}", T=T, ln=ln)
+            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
+            if half == 0:
+                self.e("s_and_b32 {sp}, {sp}, 0xffff")
+                self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
+            elif half == 1:
+                self.e("s_lshr_b32 {sp}, {sp}, 16")
+                self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
+            self.e("s_lshr_b32 {sb}, {range}, 11")
+            self.e("s_mul_i32 {sb}, {sb}, {sp}")
         self.e("s_sub_u32 {sr1}, {range}, {sb}")
         self.e("s_sub_u32 {sc1}, {code}, {sb}")          # SCC = code < bound  <=>  bit == 0
         self.e("s_cselect_b32 {range}, {sb}, {sr1}")
