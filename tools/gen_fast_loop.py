@@ -46,6 +46,7 @@ V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90"
 MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
+PS0M2 = "v78"               # PS0 - 2: indexed with len_state + 2
 CLOBBER_S = sorted(set(S.values()) | {"s92", "s93"}, key=lambda r: int(r[1:]))
 CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
 
@@ -75,7 +76,8 @@ def R(name):
 
 
 class Gen:
-    def __init__(self):
+    def __init__(self, lp0):
+        self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         self.main, self.cold, self.stubs = [], [], []
         self.cur = self.main
         self.uid = 0
@@ -246,13 +248,14 @@ class Gen:
         self.norm()
 
     # ---- pending short match ---------------------------------------------------------------------------
-    def finish_pending(self):
+    def finish_pending(self, have_t6=False):
         self.e("s_waitcnt vmcnt(0)")
         self.e("v_cmp_gt_u32 vcc, {pend_n}, {v_lane}")
         self.e("v_add_u32 {VT0}, {pend_pos}, {v_lane}")
         self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
-        self.e("s_add_u32 {t6}, {pend_n}, -1")
+        if not have_t6:
+            self.e("s_add_u32 {t6}, {pend_n}, -1")
         self.e("v_readlane_b32 {prev}, {pend_val}, {t6}")
         self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
         self.e("s_mov_b32 {pend_n}, 0")
@@ -263,7 +266,7 @@ class Gen:
 
     # ---- LenDecoder::decode ------------------------------------------------------------------------------
     def len_decode(self, which, done):
-        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (length - 2) in mlen; jumps to `done`.
+        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (the match length) in mlen; jumps to `done`.
         low[ps] / mid[ps]: heap numbering from root 4 + ps (lanes 4..31 of m_*_low / m_*_mid)."""
         p = "m_len" if which == 0 else "m_rlen"
         w = "l%d" % which
@@ -272,8 +275,8 @@ class Gen:
         self.e("s_add_u32 {sym}, {ps}, 4")
         for _ in range(3):
             self.bit(R(p + "_low"), R("sym"))
-        self.e("s_and_b32 {mlen}, {sym}, 7")
-        self.e("s_xor_b32 {mlen}, {mlen}, 7")
+        self.e("s_and_b32 {t0}, {sym}, 7")                # length = 2 + path = 9 - inverted path
+        self.e("s_sub_u32 {mlen}, 9, {t0}")
         self.e("s_branch " + self.L(done))
         self.lab(w + "_nlow")
         self.taken(R("m_ismatch"))
@@ -281,8 +284,8 @@ class Gen:
         self.e("s_add_u32 {sym}, {ps}, 4")
         for _ in range(3):
             self.bit(R(p + "_mid"), R("sym"))
-        self.e("s_and_b32 {mlen}, {sym}, 7")
-        self.e("s_xor_b32 {mlen}, {mlen}, 15")           # 8 + path
+        self.e("s_and_b32 {t0}, {sym}, 7")                # length = 10 + path
+        self.e("s_sub_u32 {mlen}, 17, {t0}")
         self.e("s_branch " + self.L(done))
         # high: tree of 8, nodes 1..63 in h0, 64..127 in h1, 128..191 in h2, 192..255 in h3
         self.lab(w + "_high")
@@ -295,8 +298,7 @@ class Gen:
         self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
         self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
         self.lab(w + "_hdone")
-        self.e("s_xor_b32 {mlen}, {sym}, 0x1ff")
-        self.e("s_add_u32 {mlen}, {mlen}, 16")
+        self.e("s_sub_u32 {mlen}, 0x211, {sym}")          # length = 18 + path = 18 + 255 - (sym - 256)
         self.e("s_branch " + self.L(done))
         self.lab(w + "_h3")
         self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
@@ -373,10 +375,13 @@ class Gen:
 
     def literal_row(self, tag):
         e, L = self.e, self.L
-        e("s_and_b32 {t0}, {len}, {lpmask}")
-        e("s_lshl_b32 {t0}, {t0}, {lc}")
-        e("s_lshr_b32 {t1}, {prev}, {lc8}")
-        e("s_add_u32 {row}, {t0}, {t1}")
+        if self.lp0:
+            e("s_lshr_b32 {row}, {prev}, {lc8}")
+        else:
+            e("s_and_b32 {t0}, {len}, {lpmask}")
+            e("s_lshl_b32 {t0}, {t0}, {lc}")
+            e("s_lshr_b32 {t1}, {prev}, {lc8}")
+            e("s_add_u32 {row}, {t0}, {t1}")
         e("s_cmp_lg_u32 {row}, {cur_row}")
         e("s_cbranch_scc1 " + L("Orow_swap" + tag))
         self.lab("lit_r" + tag)
@@ -438,11 +443,10 @@ class Gen:
         # ---- matched literal: probs[((1 + match_bit) << 8) + sym] (lzma.rs:541-555).  The row's two
         #      matched sub-tables are in LDS, dword k of a lane = nodes 64k..64k+63, low half for
         #      match_bit 0 and high half for match_bit 1.
-        e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)   # prev / mb unknown (or, entering from C++, nothing pending)
-        e("s_cbranch_scc1 " + L("Oprev_fetchM"))
-        e("s_cmp_eq_u32 {pend_n}, 0")
-        e("s_cbranch_scc1 " + L("lit_pM"))
-        self.finish_pending()
+        e("s_add_u32 {t6}, {pend_n}, -1")                # complete the pending match, unless (rare) there is none
+        e("s_cmpk_ge_u32 {t6}, 0x%x" % (PEND_UNKNOWN - 1))  # (pend_n == 0, entering from C++) or prev / mb are unknown
+        e("s_cbranch_scc1 " + L("OpendM_special"))
+        self.finish_pending(have_t6=True)
         lab("lit_pM")
         self.literal_row("M")
         e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
@@ -516,8 +520,10 @@ class Gen:
                 e("s_addc_u32 {sym}, {sym}, {sym}")
                 self.post_sym(V[T], half=half)
                 e("s_branch " + L("lm_full"))
-            lab("Oprev_fetchM")                               # lzb.last_or(0) when the previous byte is not at hand
-            self.prev_fetch("lit_pM")
+            lab("OpendM_special")
+            e("s_cmp_eq_u32 {pend_n}, 0")
+            e("s_cbranch_scc1 " + L("lit_pM"))
+            self.prev_fetch("lit_pM")                         # lzb.last_or(0) when the previous byte is not at hand
             lab("Oentry_fix")
             self.prev_fetch("topL")
 
@@ -533,30 +539,30 @@ class Gen:
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 7, 10")
         # ---- decode_distance (lzma.rs:563-592)
-        e("s_min_u32 {t5}, {mlen}, 3")                      # len_state
+        e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2
         e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
-        e("v_mov_b32 {VPS}, " + PS0)
+        e("v_mov_b32 {VPS}, " + PS0M2)
         e("s_set_gpr_idx_off")
         self.bit(V["VPS"], "1", first=True)
         for _ in range(5):
             self.bit(V["VPS"], R("sym"))
         e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
-        e("v_mov_b32 " + PS0 + ", {VPS}")
+        e("v_mov_b32 " + PS0M2 + ", {VPS}")
         e("s_set_gpr_idx_off")
         e("s_xor_b32 {t0}, {sym}, 0x7f")                    # pos_slot
-        e("s_mov_b32 {rep0}, {t0}")
         e("s_cmp_lt_u32 {t0}, 4")
-        e("s_cbranch_scc1 " + L("copy"))
+        e("s_cbranch_scc1 " + L("dist_small"))
         e("s_lshr_b32 {t1}, {t0}, 1")
         e("s_add_u32 {t1}, {t1}, -1")                       # num_direct_bits
         e("s_and_b32 {t2}, {t0}, 1")
-        e("s_or_b32 {t2}, {t2}, 2")
-        e("s_lshl_b32 {t2}, {t2}, {t1}")                    # result = (2 | (slot & 1)) << ndb
         e("s_cmp_lt_u32 {t0}, 14")
         e("s_cbranch_scc1 " + L("dist_rev"))
-        # slots >= 14: ndb - 4 direct bits, then the 4-bit align tree (m_align, heap from lane 1)
+        # slots >= 14: ndb - 4 direct bits d, then the 4-bit align tree a (m_align, heap from lane 1):
+        #   rep0 = ((2 | slot & 1) << ndb) + (d << 4) + a.  The decoders deliver the inverted values
+        #   d' = 2^(ndb-4) - 1 - d and a' = 15 - a, so rep0 = ((3 + (slot & 1)) << ndb) - ((d' << 4) + a' + 1).
+        e("s_add_u32 {t2}, {t2}, 3")
+        e("s_lshl_b32 {t2}, {t2}, {t1}")
         e("s_add_u32 {t3}, {t1}, -4")                       # count
-        e("s_mov_b32 {t5}, {t3}")
         e("s_mov_b32 {t4}, 0")
         lab("direct4")
         e("s_cmp_lt_u32 {t3}, 4")
@@ -575,22 +581,28 @@ class Gen:
         e("s_cbranch_scc0 " + L("direct_done"))
         self.direct_bit(R("t4"))
         lab("direct_done")
-        e("s_bfm_b32 {t5}, {t5}, 0")                         # (1 << count) - 1
-        e("s_andn2_b32 {t4}, {t5}, {t4}")                    # un-invert
-        e("s_lshl_b32 {t4}, {t4}, 4")
-        e("s_add_u32 {t2}, {t2}, {t4}")
         self.bit(R("m_align"), "1", first=True)
         for _ in range(3):
             self.bit(R("m_align"), R("sym"))
-        self.unreverse(4, R("t4"))
-        e("s_add_u32 {rep0}, {t2}, {t4}")
+        e("s_lshl_b32 {t4}, {t4}, 4")
+        e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
+        e("s_brev_b32 {t3}, {t3}")                           # a'
+        e("s_add_u32 {t4}, {t4}, {t3}")
+        e("s_add_u32 {t4}, {t4}, 1")
+        e("s_sub_u32 {rep0}, {t2}, {t4}")
         e("s_cmp_eq_u32 {rep0}, -1")
         e("s_cbranch_scc1 " + L("Xmarker"))
         e("s_branch " + L("copy"))
         with self.in_cold():
+            lab("dist_small")
+            e("s_mov_b32 {rep0}, {t0}")
+            e("s_branch " + L("copy"))
+        with self.in_cold():
             # slots 4..11: pos_decoders[result - slot + node] in m_posdec_a, ndb = 1..4 bits;
             # slots 12, 13: m_posdec_b lanes (slot - 12) * 32 + node, 5 bits
             lab("dist_rev")
+            e("s_or_b32 {t2}, {t2}, 2")
+            e("s_lshl_b32 {t2}, {t2}, {t1}")                    # result = (2 | (slot & 1)) << ndb
             e("s_cmp_lt_u32 {t0}, 12")
             e("s_cbranch_scc0 " + L("dist_rev_b"))
             e("s_sub_u32 {t6}, {t2}, {t0}")
@@ -625,7 +637,7 @@ class Gen:
         e("s_cmpk_lt_u32 {state}, 7")                        # short rep
         e("s_cselect_b32 {state}, 9, 11")
         e("s_mov_b32 {mlen}, 1")
-        e("s_branch " + L("copy_n"))
+        e("s_branch " + L("copy"))
         lab("rep0_long")
         self.taken(R("m_rep0long"), to="rep_len")
         lab("rep_123")
@@ -659,9 +671,7 @@ class Gen:
         e("s_cselect_b32 {state}, 8, 11")
 
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
-        lab("copy")
-        e("s_add_u32 {mlen}, {mlen}, 2")
-        lab("copy_n")                                        # mlen = bytes to copy, distance = rep0 + 1
+        lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
         e("s_add_u32 {t0}, {rep0}, 1")
         e("s_cmp_gt_u32 {t0}, {dict_size}")
         e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
@@ -752,22 +762,27 @@ class Gen:
 
 
 def main():
-    g = Gen()
-    g.build()
-    lines = g.main + g.cold + g.stubs
-    g.cur = lines
-    g.finish()
+    texts = {}
+    for name, lp0 in (("LP0", True), ("GEN", False)):
+        g = Gen(lp0)
+        g.build()
+        lines = g.main + g.cold + g.stubs
+        g.cur = lines
+        g.finish()
+        texts[name] = lines
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
-    out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring).")
+    out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
+    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, MILZMA_FAST_LOOP_TEXT_GEN for any lp.")
     out.append("// clang-format off")
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
     out.append("#define MILZMA_LOOP_PEND_UNKNOWN 0x%xu" % PEND_UNKNOWN)
-    out.append("#define MILZMA_FAST_LOOP_TEXT \\")
-    for l in lines:
-        out.append('  "%s\\n\\t" \\' % l.strip())
-    out.append('  ""')
+    for name, lines in texts.items():
+        out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
+        for l in lines:
+            out.append('  "%s\\n\\t" \\' % l.strip())
+        out.append('  ""')
     fixed = ['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(16)] + ['"+{v%d}"(d.posslot[%d])' % (80 + i, i) for i in range(4)]
     outs = ['[%s] "+s"(d.%s)' % (n, n) for n in OPS_INOUT_S] + ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V] + fixed
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
@@ -783,9 +798,9 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lzma_rs_amd", "csrc", "fast_loop_asm.inc")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
-    n_ins = sum(1 for l in lines if not l.endswith(":"))
-    print("wrote %s: %d instructions (%d in the main sequence)" % (os.path.normpath(path), n_ins,
-                                                                    sum(1 for l in g.main if not l.endswith(":"))))
+    for name, lines in texts.items():
+        print("%s: %d instructions" % (name, sum(1 for l in lines if not l.endswith(":"))))
+    print("wrote " + os.path.normpath(path))
 
 
 if __name__ == "__main__":
