@@ -249,15 +249,17 @@ class Gen:
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False):
+        # (gfx940 family: a VALU write of VCC / an SGPR wants 2 wait states before a VALU read of it, hence
+        #  the order: the v_cmp that writes vcc is never followed directly by the v_cndmask that reads it)
         self.e("s_waitcnt vmcnt(0)")
         self.e("v_cmp_gt_u32 vcc, {pend_n}, {v_lane}")
         self.e("v_add_u32 {VT0}, {pend_pos}, {v_lane}")
-        self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
         if not have_t6:
             self.e("s_add_u32 {t6}, {pend_n}, -1")
         self.e("v_readlane_b32 {prev}, {pend_val}, {t6}")
         self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
+        self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
         self.e("s_mov_b32 {pend_n}, 0")
 
     def exit_with(self, code):
@@ -391,13 +393,13 @@ class Gen:
     def build(self):
         e, lab, L = self.e, self.lab, self.L
         # prologue: per-lane constants
-        e("v_lshl_add_u32 {VL16}, {v_lane}, 4, {ldsbase}")
         e("v_cmp_eq_u32 vcc, 0, {v_lane}")
-        e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
+        e("v_lshl_add_u32 {VL16}, {v_lane}, 4, {ldsbase}")
         e("v_mov_b32 {VKTOP}, 0x1000000")
         e("v_add_u32 {VLANE64}, 64, {v_lane}")
         e("v_add_u32 {VLANE128}, 0x80, {v_lane}")
         e("v_add_u32 {VLANE192}, 0xc0, {v_lane}")
+        e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
         e("s_movk_i32 {c2017}, 2017")
         e("s_movk_i32 {c2048}, 0x800")
         # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
@@ -692,11 +694,11 @@ class Gen:
         e("v_add_u32 {VT0}, {t2}, {v_lane}")
         lab("cp_b")
         e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
-        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
         e("s_mov_b32 {pend_pos}, {len}")
         e("s_mov_b32 {pend_n}, {mlen}")
         e("s_add_u32 {len}, {len}, {mlen}")
+        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
         e("s_branch " + L("topM"))
 
         # ================= out-of-line helpers =================
