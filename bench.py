@@ -174,7 +174,7 @@ def main():
                                                  first_index=rank * n, processes=procs)
     cpu_line = None
     if world == 1 and not args.no_cpu_baseline:
-        sample = args.cpu_sample or min(1024, cores * 24)
+        sample = args.cpu_sample or min(2048, cores * 64)  # ~20 s of CPU work
         cpu_line = cpu_baseline(sample, args.size, args.kind, args.dict, cores)
 
     D.init()
@@ -237,13 +237,13 @@ def main():
     # HBM-side traffic cannot be read from inside the process: it comes from a separate
     # `rocprofv3 --pmc FETCH_SIZE` pass of this same command, summarised under profiles/.
     traffic, traffic_note = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_fast_pmc_summary.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_asm_pmc_summary.json")
     if os.path.exists(pmc_path) and args.kind == "text" and n == 4096 and args.size == 1 << 20 and args.dict == 1 << 16:
         with open(pmc_path) as f:
             pmc = json.load(f)
         traffic = pmc["derived"]["fetch_bytes_per_launch"]
         traffic_note = ("L2->fabric read bytes per launch (FETCH_SIZE, rocprofv3 --pmc pass recorded in "
-                        "profiles/r01_fast_pmc_summary.json; WRITE_SIZE pass not available)")
+                        "profiles/r01_asm_pmc_summary.json; the WRITE_SIZE pass hangs rocprofv3 on the box)")
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
