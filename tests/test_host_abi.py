@@ -5,6 +5,8 @@ import ctypes
 import os
 import re
 import struct
+import subprocess
+import sys
 
 import pytest
 
@@ -104,3 +106,21 @@ def test_result_messages_are_the_reference_strings():
     assert msg(22, 4, 1)[1] == "lzma error: LZMA2 invalid properties: lc + lp (4 + 1) must be <= 4"
     assert msg(23, 5)[1] == "lzma error: LZMA2 expected 5 uncompressed bytes: failed to fill whole buffer"
     assert msg(32)[0] == M.INFRA_ERROR
+
+
+def test_generated_asm_loop_is_current(tmp_path):
+    """lzma_rs_amd/csrc/fast_loop_asm.inc is generated: the committed file must be what the committed
+    generator produces (no hand edits, no stale output)."""
+    import importlib.util
+    import shutil
+    gen = os.path.join(ROOT, "tools", "gen_fast_loop.py")
+    inc = os.path.join(ROOT, "lzma_rs_amd", "csrc", "fast_loop_asm.inc")
+    # run a copy of the generator from a scratch tree so that the real file is not touched
+    scratch = tmp_path / "tools"
+    scratch.mkdir()
+    (tmp_path / "lzma_rs_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(gen, scratch / "gen_fast_loop.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_GEN_")}
+    subprocess.run([sys.executable, str(scratch / "gen_fast_loop.py")], check=True, env=env, stdout=subprocess.DEVNULL)
+    with open(inc) as a, open(tmp_path / "lzma_rs_amd" / "csrc" / "fast_loop_asm.inc") as b:
+        assert a.read() == b.read()

@@ -54,6 +54,8 @@ EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, 
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
 PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
 K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
+LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of the match-source load (experiments)
+STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
 
 # ---- operands -------------------------------------------------------------------------------------------
@@ -259,7 +261,7 @@ class Gen:
         self.e("v_readlane_b32 {prev}, {pend_val}, {t6}")
         self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
         self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
+        self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
 
     def exit_with(self, code):
@@ -432,7 +434,7 @@ class Gen:
         e("s_cbranch_scc1 " + L("Xlimit"))
         e("v_mov_b32 {VT0}, {prev}")
         e("v_or_b32 {VT1}, {len}, {VOOB}")
-        e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen")
+        e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen" + STORE_MOD)
         e("s_add_u32 {len}, {len}, 1")
         e("s_branch " + L("topL"))
         with self.in_cold():
@@ -698,7 +700,7 @@ class Gen:
         e("s_mov_b32 {pend_n}, {mlen}")
         e("s_add_u32 {len}, {len}, {mlen}")
         e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen")
+        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
         e("s_branch " + L("topM"))
 
         # ================= out-of-line helpers =================
