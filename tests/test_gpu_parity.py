@@ -181,6 +181,46 @@ def test_symbol_streams_every_lclppb(ctx):
         assert d.ok
 
 
+def test_symbol_streams_stress(ctx):
+    # many longer random symbol sequences inside the fast kernels' property class (pb <= 2, lc + lp <= 3):
+    # every symbol kind after every other, short / 64+ byte / self-overlapping matches, all rep indices,
+    # known-size and end-marker termination; a third of them with a few corrupted payload bytes
+    rng = random.Random(2026)
+    comps = []
+    for trial in range(400):
+        lc = rng.choice([0, 1, 2, 3])
+        lp = rng.randint(0, 3 - lc)
+        pb = rng.randint(0, 2)
+        enc = E.LzmaSymbolEncoder(lc, lp, pb)
+        n = 0
+        for _ in range(rng.randint(1, 1500)):
+            r = rng.random()
+            if n == 0 or r < 0.5:
+                s = ("lit", rng.choice([rng.randrange(256), 0x20, 0x65]))
+            elif r < 0.75:
+                dist = rng.randint(1, n) if rng.random() < 0.5 else rng.randint(1, min(n, 40))
+                s = ("match", rng.randint(2, rng.choice([3, 8, 70, 273])), dist)
+            elif r < 0.9:
+                idx = rng.randint(0, 3)
+                s = ("rep", idx, rng.randint(2, rng.choice([6, 90]))) if enc.rep[idx] + 1 <= n else ("lit", 7)
+            else:
+                s = ("shortrep",) if enc.rep[0] + 1 <= n else ("lit", 9)
+            enc.encode([s])
+            n = len(enc.out)
+        marker = rng.random() < 0.4
+        if marker:
+            enc.encode([("marker",)])
+        comp = bytearray(E.lzma_header(lc, lp, pb, rng.choice([1 << 12, 1 << 16, 1 << 20]), None if marker else n) +
+                         enc.finish())
+        if trial % 3 == 2 and len(comp) > 20:
+            for _ in range(rng.randint(1, 3)):
+                comp[rng.randrange(13, len(comp))] ^= 1 << rng.randrange(8)
+        comps.append(bytes(comp))
+    decs = ctx.lzma_batch(comps)
+    for comp, d in zip(comps, decs):
+        same(d, orc.lzma_decompress(comp))
+
+
 def test_error_sites_match_oracle(ctx):
     lits = [("lit", c) for c in b"abcdefgh"]
     many = [("lit", i & 0xFF) for i in range(6000)]
