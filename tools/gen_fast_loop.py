@@ -281,32 +281,33 @@ class Gen:
             self.bit(R(p + "_low"), R("sym"))
         self.e("s_and_b32 {t0}, {sym}, 7")                # length = 2 + path = 9 - inverted path
         self.e("s_sub_u32 {mlen}, 9, {t0}")
-        self.e("s_branch " + self.L(done))
-        self.lab(w + "_nlow")
-        self.taken(R("m_ismatch"))
-        self.decide(R("m_ismatch"), choice2, w + "_high")
-        self.e("s_add_u32 {sym}, {ps}, 4")
-        for _ in range(3):
-            self.bit(R(p + "_mid"), R("sym"))
-        self.e("s_and_b32 {t0}, {sym}, 7")                # length = 10 + path
-        self.e("s_sub_u32 {mlen}, 17, {t0}")
-        self.e("s_branch " + self.L(done))
-        # high: tree of 8, nodes 1..63 in h0, 64..127 in h1, 128..191 in h2, 192..255 in h3
-        self.lab(w + "_high")
-        self.taken(R("m_ismatch"))
-        self.bit(R(p + "_h0"), "1", first=True)
-        for _ in range(5):
-            self.bit(R(p + "_h0"), R("sym"))
-        self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
-        self.e("s_bitcmp1_b32 {sym}, 6")
-        self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
-        self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
-        self.lab(w + "_hdone")
-        self.e("s_sub_u32 {mlen}, 0x211, {sym}")          # length = 18 + path = 18 + 255 - (sym - 256)
-        self.e("s_branch " + self.L(done))
-        self.lab(w + "_h3")
-        self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
-        self.e("s_branch " + self.L(w + "_hdone"))
+        self.lab(done)                                    # the common (short) lengths fall through
+        with self.in_cold():
+            self.lab(w + "_nlow")
+            self.taken(R("m_ismatch"))
+            self.decide(R("m_ismatch"), choice2, w + "_high")
+            self.e("s_add_u32 {sym}, {ps}, 4")
+            for _ in range(3):
+                self.bit(R(p + "_mid"), R("sym"))
+            self.e("s_and_b32 {t0}, {sym}, 7")            # length = 10 + path
+            self.e("s_sub_u32 {mlen}, 17, {t0}")
+            self.e("s_branch " + self.L(done))
+            # high: tree of 8, nodes 1..63 in h0, 64..127 in h1, 128..191 in h2, 192..255 in h3
+            self.lab(w + "_high")
+            self.taken(R("m_ismatch"))
+            self.bit(R(p + "_h0"), "1", first=True)
+            for _ in range(5):
+                self.bit(R(p + "_h0"), R("sym"))
+            self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
+            self.e("s_bitcmp1_b32 {sym}, 6")
+            self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
+            self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
+            self.e("s_sub_u32 {mlen}, 0x211, {sym}")      # length = 18 + path = 18 + 255 - (sym - 256)
+            self.e("s_branch " + self.L(done))
+            self.lab(w + "_h3")
+            self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
+            self.e("s_sub_u32 {mlen}, 0x211, {sym}")
+            self.e("s_branch " + self.L(done))
 
     def reverse_tree_based(self, T, base_reg, nbits, out):
         """parse_reverse_bit_tree (rangecoder.rs:136-151), node n at lane base + n"""
@@ -377,6 +378,17 @@ class Gen:
             e("s_cbranch_scc0 " + L("Xdone_fin"))
             e("s_branch " + L("top2" + tag))
 
+    def literal_epilogue(self):
+        e, L = self.e, self.L
+        e("s_xor_b32 {prev}, {sym}, 0x1ff")             # (0x100 | inverted path) -> byte
+        e("s_cmp_ge_u32 {len}, {out_lim}")
+        e("s_cbranch_scc1 " + L("Xlimit"))
+        e("v_mov_b32 {VT0}, {prev}")
+        e("v_or_b32 {VT1}, {len}, {VOOB}")
+        e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen" + STORE_MOD)
+        e("s_add_u32 {len}, {len}, 1")
+        e("s_branch " + L("topL"))
+
     def literal_row(self, tag):
         e, L = self.e, self.L
         if self.lp0:
@@ -429,18 +441,11 @@ class Gen:
         e("s_cbranch_scc1 " + L("plain7_hi"))
         self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
         lab("lit_done")
-        e("s_xor_b32 {prev}, {sym}, 0x1ff")             # (0x100 | inverted path) -> byte
-        e("s_cmp_ge_u32 {len}, {out_lim}")
-        e("s_cbranch_scc1 " + L("Xlimit"))
-        e("v_mov_b32 {VT0}, {prev}")
-        e("v_or_b32 {VT1}, {len}, {VOOB}")
-        e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen" + STORE_MOD)
-        e("s_add_u32 {len}, {len}, 1")
-        e("s_branch " + L("topL"))
+        self.literal_epilogue()
         with self.in_cold():
             lab("plain7_hi")
             self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
-            e("s_branch " + L("lit_done"))
+            self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
 
         # ================= after a match =================
         self.symbol_top("M")
@@ -468,38 +473,41 @@ class Gen:
         e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
         e("ds_read_b128 " + MROW + ", {VA}")
         e("s_waitcnt lgkmcnt(0)")
-        for i in range(7):          # levels 0..6: a mismatch continues in the plain chain
-            lab("lm%d" % i)
-            first = i == 0
-            T = V["M0"] if i < 6 else V["M1"]
-            lnreg = "1" if first else R("sym")
-            cl = V["VLANE64"] if i == 6 else None
-            acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
-            e("s_bitcmp1_b32 {mb}, %d" % (7 - i))           # the match byte's next bit picks the sub-table
-            e("s_cbranch_scc1 " + L("lm%d_m1" % i))
-            mis0, mis1 = self.new("MIS"), self.new("MIS")
-            self.core(T, lnreg, half=0, cmp_lane=cl)          # match bit 0: still matched if the bit is 0 (SCC = 1)
-            e("s_cbranch_scc0 " + L(mis0))
-            e(acc)
-            self.post_known(T, True, half=0)
-            self.norm()                                      # falls through to the next level
-            with self.in_cold():
-                lab(mis0)
+        # levels 0..6 (a mismatch continues in the plain chain): one code chain per value of the match
+        # bit, so that a branch is only taken when the match bit differs from the previous level's
+        e("s_bitcmp1_b32 {mb}, 7")
+        e("s_cbranch_scc1 " + L("lm0_1"))
+        for m in (0, 1):
+            ctx = None if m == 0 else self.in_cold()
+            if ctx:
+                ctx.__enter__()
+            for i in range(7):
+                lab("lm%d_%d" % (i, m))
+                first = i == 0
+                T = V["M0"] if i < 6 else V["M1"]
+                lnreg = "1" if first else R("sym")
+                cl = V["VLANE64"] if i == 6 else None
+                acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
+                mis = self.new("MIS")
+                self.core(T, lnreg, half=m, cmp_lane=cl)
+                # still matched if the decoded bit equals the match bit: SCC = (bit == 0)
+                e(("s_cbranch_scc0 " if m == 0 else "s_cbranch_scc1 ") + L(mis))
                 e(acc)
-                self.post_known(T, False, half=0)
-                e("ds_write_b128 {VA}, " + MROW)
-                self.norm(to="plain%d" % (i + 1))
-                lab("lm%d_m1" % i)
-                self.core(T, lnreg, half=1, cmp_lane=cl)      # match bit 1: still matched if the bit is 1 (SCC = 0)
-                e("s_cbranch_scc1 " + L(mis1))
-                e(acc)
-                self.post_known(T, False, half=1)
-                self.norm(to="lm%d" % (i + 1))
-                lab(mis1)
-                e(acc)
-                self.post_known(T, True, half=1)
-                e("ds_write_b128 {VA}, " + MROW)
-                self.norm(to="plain%d" % (i + 1))
+                self.post_known(T, m == 0, half=m)
+                self.norm()
+                with Gen._Into(self, self.stubs):         # (not the cold list: the m == 1 chain lives there)
+                    lab(mis)
+                    e(acc)
+                    self.post_known(T, m != 0, half=m)
+                    e("ds_write_b128 {VA}, " + MROW)
+                    self.norm(to="plain%d" % (i + 1))
+                if i < 6:
+                    e("s_bitcmp1_b32 {mb}, %d" % (7 - (i + 1)))   # the next match bit picks the sub-table
+                    e(("s_cbranch_scc1 " if m == 0 else "s_cbranch_scc0 ") + L("lm%d_%d" % (i + 1, 1 - m)))
+                elif m == 1:
+                    e("s_branch " + L("lm7"))
+            if ctx:
+                ctx.__exit__()
         lab("lm7")                   # last level: nodes 128..191 in M2, 192..255 in M3; nothing follows a mismatch
         e("s_bitcmp1_b32 {sym}, 6")
         e("s_cbranch_scc1 " + L("lm7_hi"))
@@ -539,7 +547,6 @@ class Gen:
         e("s_mov_b32 {rep2}, {rep1}")
         e("s_mov_b32 {rep1}, {rep0}")
         self.len_decode(0, "len0_done")
-        lab("len0_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 7, 10")
         # ---- decode_distance (lzma.rs:563-592)
@@ -670,7 +677,6 @@ class Gen:
         e("s_mov_b32 {rep0}, {t0}")
         lab("rep_len")
         self.len_decode(1, "len1_done")
-        lab("len1_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 8, 11")
 
