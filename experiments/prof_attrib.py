@@ -9,6 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MILZMA_KERNEL", "fast")  # the attribution macros live in the C++ fast kernel
 os.environ.setdefault("MILZMA_LIB", os.path.join(ROOT, "lzma_rs_amd", "libmilzma_prof.so"))
 import torch  # noqa: E402
 import lzma_rs_amd as M  # noqa: E402
