@@ -35,10 +35,21 @@ Conventions inside the loop
 import os
 import re
 
+PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
+K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
+LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of the match-source load (experiments)
+STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
+WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
+INTERLEAVE = os.environ.get("MILZMA_GEN_INTERLEAVE", "0") == "1"  # alternate scalar and vector instructions inside a tree decision (measured: -1 %)
+PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
+# matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
+BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
+
+
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91")
+         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96")
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
@@ -47,20 +58,14 @@ MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
 PS0M2 = "v78"               # PS0 - 2: indexed with len_state + 2
-CLOBBER_S = sorted(set(S.values()) | {"s92", "s93"}, key=lambda r: int(r[1:]))
+CLOBBER_S = sorted(set(S.values()) | {"s92", "s93"} | ({"s97", "s98", "s99"} if WAITPROF else set()), key=lambda r: int(r[1:]))  # (+ the refill return address)
 CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
-PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
-K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
-LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of the match-source load (experiments)
-STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
-BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
-
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
-               "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode"]
+               "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc"]
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
                "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val"]
@@ -220,12 +225,29 @@ class Gen:
     def bit(self, T, ln, half=None, first=False, cmp_lane=None):
         """one tree decision: sym = 2 * sym + (bit == 0), then normalise.  first: sym was 1 (not
         materialised), ln is the constant lane of the root."""
+        acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
+        if INTERLEAVE and half is None and BOUND_ON_VALU and not K_ON_VALU:
+            # same instructions as below, ordered so that scalar and vector ones alternate where the
+            # dependencies allow: the 4 waves of a SIMD then less often all want the same pipe
+            e = self.e
+            e("v_lshrrev_b32 {vt}, 11, {range}")
+            e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
+            e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
+            e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
+            e("s_sub_u32 {sr1}, {range}, {sb}")
+            e("s_sub_u32 {sc1}, {code}, {sb}")              # SCC = code < bound  <=>  bit == 0
+            e("s_cselect_b32 {sk}, {c2048}, 31")
+            e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
+            e("s_cselect_b32 {range}, {sb}, {sr1}")
+            e("v_lshrrev_b32 {vt}, 5, {vt}")
+            e("s_cselect_b32 {code}, {code}, {sc1}")
+            e(acc)
+            e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
+            self.norm()
+            return
         self.core(T, ln, half, cmp_lane)
         self.pre_sym()
-        if first:
-            self.e("s_cselect_b32 {sym}, 3, 2")
-        else:
-            self.e("s_addc_u32 {sym}, {sym}, {sym}")
+        self.e(acc)
         self.post_sym(T, half)
         self.norm()
 
@@ -250,7 +272,17 @@ class Gen:
         self.norm()
 
     # ---- pending short match ---------------------------------------------------------------------------
-    def finish_pending(self, have_t6=False):
+    def finish_pending(self, have_t6=False, prof=None):
+        if WAITPROF and prof:
+            self.e("s_memtime s[98:99]")
+            self.e("s_waitcnt lgkmcnt(0)")
+            self.e("s_mov_b32 s97, s98")
+            self.e("s_waitcnt vmcnt(0)")
+            self.e("s_memtime s[98:99]")
+            self.e("s_waitcnt lgkmcnt(0)")
+            self.e("s_sub_u32 s97, s98, s97")
+            self.e("s_add_u32 {w}, {w}, s97", w=R("prof_w" + prof))
+            self.e("s_add_u32 {n}, {n}, 1", n=R("prof_n" + prof))
         # (gfx940 family: a VALU write of VCC / an SGPR wants 2 wait states before a VALU read of it, hence
         #  the order: the v_cmp that writes vcc is never followed directly by the v_cndmask that reads it)
         self.e("s_waitcnt vmcnt(0)")
@@ -455,7 +487,7 @@ class Gen:
         e("s_add_u32 {t6}, {pend_n}, -1")                # complete the pending match, unless (rare) there is none
         e("s_cmpk_ge_u32 {t6}, 0x%x" % (PEND_UNKNOWN - 1))  # (pend_n == 0, entering from C++) or prev / mb are unknown
         e("s_cbranch_scc1 " + L("OpendM_special"))
-        self.finish_pending(have_t6=True)
+        self.finish_pending(have_t6=True, prof="m")
         lab("lit_pM")
         self.literal_row("M")
         e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
@@ -583,6 +615,20 @@ class Gen:
         e("s_add_u32 {t3}, {t3}, -4")
         e("s_branch " + L("direct4"))
         lab("direct_tail")
+        if PREFETCH:
+            # t3 = r direct bits (0..3) and the 4 align bits are still to come: the distance is known to within
+            # 2^(r+4) bytes.  rep0 + 1 lies in (R0 - 2^(r+4), R0] with R0 = t2 - (t4 << (r+4)), so the source starts
+            # in [len - R0, len - R0 + 2^(r+4)): pull those lines towards L2 now with (dummy) scalar loads -- the
+            # copy's vector load, ~100 instructions from here, otherwise pays the full dictionary-read latency.
+            e("s_add_u32 {t5}, {t3}, 4")
+            e("s_lshl_b32 {t5}, {t4}, {t5}")
+            e("s_sub_u32 {t5}, {t2}, {t5}")
+            e("s_sub_u32 {t5}, {len}, {t5}")
+            e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
+            e("s_add_u32 {t6}, {t5}, 64")
+            e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
+            e("s_add_u32 {t6}, {t5}, 0x80")
+            e("s_buffer_load_dword {pf2}, {out_rsrc}, {t6}")
         e("s_bitcmp1_b32 {t3}, 1")
         e("s_cbranch_scc0 " + L("direct_t1"))
         for _ in range(2):
@@ -676,6 +722,12 @@ class Gen:
         e("s_mov_b32 {rep1}, {rep0}")
         e("s_mov_b32 {rep0}, {t0}")
         lab("rep_len")
+        if PREFETCH:                                          # the distance is known before the length is decoded
+            e("s_add_u32 {t5}, {rep0}, 1")
+            e("s_sub_u32 {t5}, {len}, {t5}")
+            e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
+            e("s_add_u32 {t6}, {t5}, 64")
+            e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
         self.len_decode(1, "len1_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 8, 11")
@@ -726,7 +778,7 @@ class Gen:
             lab("Opend_copy")
             e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
             e("s_cbranch_scc1 " + L("Opend_clear"))
-            self.finish_pending()
+            self.finish_pending(prof="c")
             e("s_branch " + L("cp_a"))
             lab("Opend_clear")
             e("s_mov_b32 {pend_n}, 0")
