@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""configs[4] of BASELINE.json as a timing probe (not a bench.py line): N .xz files of 4 MiB
+(text | 200 KB random | text; 1 MiB blocks; CRC64) through milzma_xz_decompress_batch, host buffers in and out.
+Usage: python experiments/xz_batch_bench.py [files=1024] [distinct=32]"""
+import ctypes
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+import lzma_rs_amd as M  # noqa: E402
+from lzma_rs_amd import workloads as W  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+
+
+def one(i):
+    half = (4 * 1048576 - 200_000) // 2
+    plain = W.make_plain("text", half, seed=100 + i) + W.make_plain("random", 200_000, seed=200 + i) + \
+        W.make_plain("text", 4 * 1048576 - 200_000 - half, seed=300 + i)
+    return W.compress_xz_blocks(plain, block_size=1 << 20, check="crc64"), plain
+
+
+t0 = time.time()
+with ThreadPoolExecutor(16) as ex:
+    made = list(ex.map(one, range(distinct)))
+print("generated %d distinct files in %.1f s" % (distinct, time.time() - t0))
+files = [made[i % distinct][0] for i in range(n)]
+ctx = M.Context(0)
+lib = M.lib()
+bufs = [M._as_buffer(d) for d in files]
+ptrs = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+lens = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+for rep in range(2):
+    outs = (M._COutput * n)()
+    t0 = time.time()
+    lib.milzma_xz_decompress_batch(ctx._h, n, ptrs, lens, outs)
+    dt = time.time() - t0
+    total = sum(outs[i].len for i in range(n))
+    ok = sum(1 for i in range(n) if outs[i].kind == 0)
+    launches = ctypes.c_uint32(0)
+    kms = lib.milzma_last_kernel_ms(ctx._h, ctypes.byref(launches))
+    print("run %d: %d files, %d ok, %.2f GiB out in %.3f s = %.2f GB/s (last decode call: kernel %.1f ms, %d launches)" %
+          (rep, n, ok, total / 2**30, dt, total / dt / 1e9, kms, launches.value))
+    if rep == 0:
+        assert ctypes.string_at(outs[0].data, outs[0].len) == made[0][1], "first file differs from its plaintext"
+    for i in range(n):
+        if outs[i].data:
+            lib.milzma_free(ctypes.cast(outs[i].data, ctypes.c_void_p))

@@ -188,6 +188,14 @@ int milzma_lzma2_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *co
 int milzma_xz_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
                                const size_t *in_lens, milzma_output *outs);
 
+/* CRC-32 (ISO-HDLC) and CRC-64/XZ of what each unit decoded, computed on the GPU over the device-resident
+ * output of a milzma_decode_units call with the same units / d_out / results: the digest step of
+ * validate_block_check (src/decode/xz.rs:292-333) with the polynomials of src/xz/crc.rs:1-4, without a
+ * host pass over the output.  crc32 / crc64: n host values each (either may be NULL); a unit whose status
+ * is not OK gets 0. */
+int milzma_crc_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_out,
+                     const milzma_result *results, uint32_t *crc32, uint64_t *crc64, void *hip_stream);
+
 /* ---- host-side parsing, usable without a GPU (and tested without one) -------------------- */
 
 /* LzmaParams::read_header (src/decode/lzma.rs:96-161): fills lc/lp/pb/dict_size/unpacked_size/

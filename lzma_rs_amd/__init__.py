@@ -133,7 +133,7 @@ class _COutput(ctypes.Structure):
 
 EXPORTS = [
     "milzma_abi_version", "milzma_create", "milzma_destroy", "milzma_last_error",
-    "milzma_decode_units", "milzma_decode_units_host", "milzma_last_kernel_ms",
+    "milzma_decode_units", "milzma_decode_units_host", "milzma_last_kernel_ms", "milzma_crc_units",
     "milzma_result_message", "milzma_default_options", "milzma_free",
     "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
     "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
@@ -169,6 +169,8 @@ def lib():
     L.milzma_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result), vp]
     L.milzma_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz,
                                            ctypes.POINTER(Result)]
+    L.milzma_crc_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, ctypes.POINTER(Result),
+                                   ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), vp]
     L.milzma_last_kernel_ms.restype = ctypes.c_float
     L.milzma_last_kernel_ms.argtypes = [vp, ctypes.POINTER(u32)]
     L.milzma_result_message.argtypes = [ctypes.POINTER(Result), u32, ctypes.c_char_p, sz]
@@ -276,6 +278,17 @@ class Context:
         launches = ctypes.c_uint32()
         ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
         return results, ms, launches.value
+
+    def crc_units(self, units, results, d_out, stream=0):
+        """CRC-32 / CRC-64(XZ) of each unit's decoded (device-resident) output, computed on the GPU.
+        Returns (list of crc32, list of crc64)."""
+        n = len(units)
+        c32 = (ctypes.c_uint32 * n)()
+        c64 = (ctypes.c_uint64 * n)()
+        r = lib().milzma_crc_units(self._h, units, n, ctypes.c_void_p(d_out), results, c32, c64, ctypes.c_void_p(stream))
+        if r != OK:
+            raise InfraError("milzma_crc_units: " + self.last_error())
+        return list(c32), list(c64)
 
     def decode_units_host(self, units, h_in, out_bytes):
         """Host-resident variant: h_in bytes-like; returns (results, bytearray output)."""

@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -33,6 +35,10 @@ struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
 };
+struct PinBuf {  // page-locked host staging (hipHostMalloc): PCIe copies run at link speed from / to it
+  void* p = nullptr;
+  size_t cap = 0;
+};
 
 thread_local std::string g_create_error;
 
@@ -41,7 +47,9 @@ thread_local std::string g_create_error;
 struct milzma_ctx {
   int device = 0;
   std::string err;
-  DevBuf units, order, results, scratch, in, out;
+  DevBuf units, order, results, scratch, in, out, crc;
+  PinBuf pin_in, pin_out, pin_small;
+  std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   uint32_t last_launches = 0;
@@ -80,6 +88,45 @@ void dev_release(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
+}
+
+bool pin_reserve(milzma_ctx* ctx, PinBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return true;
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = (std::max(bytes, size_t(1) << 16) + 4095) & ~size_t(4095);
+  if (!hip_ok(ctx, hipHostMalloc(&b.p, want, hipHostMallocDefault), "hipHostMalloc")) return false;
+  b.cap = want;
+  return true;
+}
+
+void pin_release(PinBuf& b) {
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+unsigned host_threads() {
+  if (const char* e = getenv("MILZMA_HOST_THREADS")) return unsigned(std::max(1, atoi(e)));
+  const unsigned hw = std::thread::hardware_concurrency();
+  return std::min(16u, std::max(1u, hw));
+}
+
+// runs fn(i) for i in [0, n) on up to host_threads() threads
+template <class F>
+void parallel_for(size_t n, F fn) {
+  const unsigned t = unsigned(std::min<size_t>(host_threads(), n));
+  if (t <= 1) {
+    for (size_t i = 0; i < n; i++) fn(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned k = 0; k < t; k++)
+    pool.emplace_back([=] {
+      for (size_t i = k; i < n; i += t) fn(i);
+    });
+  for (auto& th : pool) th.join();
 }
 
 }  // namespace
@@ -126,6 +173,10 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   dev_release(ctx->scratch);
   dev_release(ctx->in);
   dev_release(ctx->out);
+  dev_release(ctx->crc);
+  pin_release(ctx->pin_in);
+  pin_release(ctx->pin_out);
+  pin_release(ctx->pin_small);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -415,6 +466,112 @@ extern "C" uint64_t milzma_crc64(const uint8_t* p, size_t n) {
   }
   while (n--) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
   return ~c;
+}
+
+// ---- folding the per-chunk CRCs the GPU computes (crc_units.hip.h) -------------------------------
+// crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B) for CRCs whose init and xorout are both all ones
+// (true for CRC-32/ISO-HDLC and CRC-64/XZ); products are taken in the reflected representation, where
+// the top bit stands for x^0.
+namespace {
+
+template <class T>
+struct Gf2 {
+  T poly, top;
+  T x2n[64];  // x^(2^k) mod P
+  Gf2(T poly_, T top_) : poly(poly_), top(top_) {
+    x2n[0] = top >> 1;  // x^1
+    for (int k = 1; k < 64; k++) x2n[k] = mul(x2n[k - 1], x2n[k - 1]);
+  }
+  T mul(T a, T b) const {
+    T m = top, p = 0;
+    for (;;) {
+      if (a & m) {
+        p ^= b;
+        if ((a & (m - 1)) == 0) break;
+      }
+      m >>= 1;
+      b = (b & 1) ? (b >> 1) ^ poly : b >> 1;
+    }
+    return p;
+  }
+  T xpow8(uint64_t nbytes) const {  // x^(8 * nbytes) mod P
+    T p = top;
+    for (int k = 3; nbytes; nbytes >>= 1, k++)
+      if (nbytes & 1) p = mul(x2n[k & 63], p);
+    return p;
+  }
+};
+const Gf2<uint32_t>& gf32() {
+  static const Gf2<uint32_t> g(0xEDB88320u, 0x80000000u);
+  return g;
+}
+const Gf2<uint64_t>& gf64() {
+  static const Gf2<uint64_t> g(0xC96C5795D7870F42ull, uint64_t(1) << 63);
+  return g;
+}
+
+// parts: the kCrcPartsBytes record of one unit; len = the unit's out_len
+void crc_fold(const uint8_t* parts, uint64_t len, uint32_t* crc32, uint64_t* crc64) {
+  const uint32_t* c32 = reinterpret_cast<const uint32_t*>(parts);
+  const uint64_t* c64 = reinterpret_cast<const uint64_t*>(parts + 64 * 4);
+  uint32_t chunk;
+  memcpy(&chunk, parts + 64 * 4 + 64 * 8, 4);
+  const uint32_t s32 = gf32().xpow8(chunk);
+  const uint64_t s64 = gf64().xpow8(chunk);
+  uint32_t a32 = 0;
+  uint64_t a64 = 0;
+  uint64_t done = 0;
+  for (int l = 0; l < 64 && done < len; l++) {
+    const uint64_t n = std::min<uint64_t>(chunk, len - done);
+    if (n == chunk) {
+      a32 = gf32().mul(s32, a32) ^ c32[l];
+      a64 = gf64().mul(s64, a64) ^ c64[l];
+    } else {
+      a32 = gf32().mul(gf32().xpow8(n), a32) ^ c32[l];
+      a64 = gf64().mul(gf64().xpow8(n), a64) ^ c64[l];
+    }
+    done += n;
+  }
+  *crc32 = a32;
+  *crc64 = a64;
+}
+
+}  // namespace
+
+extern "C" int milzma_crc_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_out,
+                                const milzma_result* results, uint32_t* crc32, uint64_t* crc64, void* hip_stream) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (n == 0) return MILZMA_OK;
+  if (!units || !results) {
+    ctx->err = "null units/results";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  std::vector<uint8_t> parts(size_t(n) * kCrcPartsBytes);
+  if (!dev_reserve(ctx, ctx->units, size_t(n) * sizeof(milzma_unit)) ||
+      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)) ||
+      !dev_reserve(ctx, ctx->crc, parts.size()))
+    return MILZMA_INFRA_ERROR;
+  if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
+              "H2D units") ||
+      !hip_ok(ctx, hipMemcpyAsync(ctx->results.p, results, size_t(n) * sizeof(milzma_result), hipMemcpyHostToDevice, stream),
+              "H2D results") ||
+      !hip_ok(ctx,
+              launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), n, static_cast<const uint8_t*>(d_out),
+                               static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, stream),
+              "crc kernel launch") ||
+      !hip_ok(ctx, hipMemcpyAsync(parts.data(), ctx->crc.p, parts.size(), hipMemcpyDeviceToHost, stream), "D2H crc parts") ||
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+    return MILZMA_INFRA_ERROR;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t a = 0;
+    uint64_t b = 0;
+    if (results[i].status == MILZMA_ST_OK) crc_fold(parts.data() + size_t(i) * kCrcPartsBytes, results[i].out_len, &a, &b);
+    if (crc32) crc32[i] = a;
+    if (crc64) crc64[i] = b;
+  }
+  return MILZMA_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,6 +933,9 @@ struct Payload {
   milzma_result res;
   const uint8_t* data = nullptr;  // res.out_len bytes (valid when res.status == OK)
   std::vector<uint8_t> own;       // backing store when decoded on demand
+  bool has_crc = false;           // crc32 / crc64 of data were computed on the GPU (milzma_crc_units' kernel)
+  uint32_t crc32 = 0;
+  uint64_t crc64 = 0;
 };
 // Decodes the LZMA2 stream that starts at in[0]; the reader's EOF is in_len.
 using PayloadFn = std::function<bool(const uint8_t* in, size_t in_len, size_t cap_hint, Payload*)>;
@@ -785,7 +945,30 @@ struct Record {
 };
 
 // read_block (src/decode/xz.rs:196-290); block_start = position of the header-size byte
-int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, std::vector<uint8_t>& output, int check,
+// The file's output: grows by realloc and is handed to milzma_output as is (milzma_free = free).
+struct OutBuf {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  ~OutBuf() { free(p); }
+  bool reserve(size_t want) {
+    if (want <= cap) return true;
+    size_t c = std::max(want, cap + cap / 2);
+    c = std::max<size_t>(c, 4096);
+    void* q = realloc(p, c);
+    if (!q) return false;
+    p = static_cast<uint8_t*>(q);
+    cap = c;
+    return true;
+  }
+  bool append(const uint8_t* src, size_t len) {
+    if (!reserve(n + len)) return false;
+    if (len) memcpy(p + n, src, len);
+    n += len;
+    return true;
+  }
+};
+
+int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, OutBuf& output, int check,
                std::vector<Record>& records, uint8_t hsize_byte, const PayloadFn& decode, milzma_output* o) {
   const uint64_t header_size = (uint64_t(hsize_byte) << 2) - 1;
   BlockHeader bh;
@@ -843,21 +1026,21 @@ int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, std::vector<uint8
     case CHECK_CRC32: {
       uint32_t want;
       if (!c.u32le(&want)) return out_io_eof(o);
-      const uint32_t got = milzma_crc32(cur.data, size_t(unpacked_size));
+      const uint32_t got = cur.has_crc ? cur.crc32 : milzma_crc32(cur.data, size_t(unpacked_size));
       if (want != got) return out_fail(o, MILZMA_XZ_ERROR, "Invalid block CRC32, expected 0x%08x but got 0x%08x", want, got);
       break;
     }
     case CHECK_CRC64: {
       uint64_t want;
       if (!c.u64le(&want)) return out_io_eof(o);
-      const uint64_t got = milzma_crc64(cur.data, size_t(unpacked_size));
+      const uint64_t got = cur.has_crc ? cur.crc64 : milzma_crc64(cur.data, size_t(unpacked_size));
       if (want != got)
         return out_fail(o, MILZMA_XZ_ERROR, "Invalid block CRC64, expected 0x%016" PRIx64 " but got 0x%016" PRIx64, want, got);
       break;
     }
     default: return out_fail(o, MILZMA_XZ_ERROR, "Unsupported SHA-256 checksum (not yet implemented)");
   }
-  output.insert(output.end(), cur.data, cur.data + size_t(unpacked_size));
+  if (!output.append(cur.data, size_t(unpacked_size))) return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
   records.push_back(Record{uint64_t(c.pos - block_start - padding), unpacked_size});
   return MILZMA_OK;
 }
@@ -899,16 +1082,21 @@ int check_index(Cursor& c, size_t index_start, const std::vector<Record>& record
 }
 
 // xz::decode_stream (src/decode/xz.rs:18-94) + StreamHeader::parse (src/xz/header.rs:20-51)
-int xz_walk(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const PayloadFn& decode, milzma_output* o) {
+int xz_walk(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const PayloadFn& decode, milzma_output* o,
+            size_t out_hint = 0) {
   static const uint8_t kMagic[6] = {0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00};
   out_reset(o);
   Cursor c{in, 0, in_len};
-  std::vector<uint8_t> output;
+  OutBuf output;
+  (void)output.reserve(std::max<size_t>(out_hint, 1));
   std::vector<Record> records;
   int r = MILZMA_OK;
   auto done = [&](int rr) {
     o->in_consumed = c.pos;
-    if (!out_set_data(o, output.data(), output.size())) return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
+    if (!output.p && !output.reserve(1)) return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
+    o->data = output.p;  // ownership moves to the caller (milzma_free)
+    o->len = output.n;
+    output.p = nullptr;
     return rr;
   };
   uint8_t tag[6];
@@ -1038,6 +1226,7 @@ bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blo
 
 extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                           milzma_output* outs) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
   // 1. plan: every block the Index of a file names becomes one LZMA2 unit of a single launch
   struct Ref {
     uint32_t file;
@@ -1046,7 +1235,8 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
   std::vector<milzma_unit> units;
   std::vector<Ref> refs;
   size_t in_total = 0, out_total = 0;
-  std::vector<size_t> file_in_off(n, 0);
+  std::vector<size_t> file_in_off(n, 0), file_out_hint(n, 0);
+  std::vector<uint8_t> planned(n, 0);
   for (uint32_t i = 0; i < n; i++) {
     std::vector<PlannedBlock> blocks;
     if (!plan_from_index(ins[i], in_lens[i], &blocks)) continue;
@@ -1060,42 +1250,70 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
       u.out_off = out_total;
       u.out_cap = round_up(size_t(b.unpacked) + 16, 256);
       out_total += size_t(u.out_cap);
+      file_out_hint[i] += size_t(b.unpacked);
       units.push_back(u);
       refs.push_back(Ref{i, b.data_off});
     }
-    if (!blocks.empty()) in_total += round_up(in_lens[i], 256);
-  }
-  std::vector<uint8_t> hin(in_total), hout(out_total);
-  std::vector<milzma_result> res(units.size());
-  if (!units.empty()) {
-    {
-      uint32_t last = UINT32_MAX;
-      for (const auto& r : refs)
-        if (r.file != last) {
-          memcpy(hin.data() + file_in_off[r.file], ins[r.file], in_lens[r.file]);
-          last = r.file;
-        }
+    if (!blocks.empty()) {
+      planned[i] = 1;
+      in_total += round_up(in_lens[i], 256);
     }
-    if (milzma_decode_units_host(ctx, units.data(), uint32_t(units.size()), hin.data(), in_total, hout.data(), out_total,
-                                 res.data()) != MILZMA_OK) {
+  }
+  // 2. one launch for all planned blocks.  Input and output are staged through page-locked buffers (PCIe at
+  //    link speed); the blocks' CRC-32 / CRC-64 are computed on the GPU while the output is still there, so
+  //    the host never has to read the decoded bytes except to hand them to the caller.
+  const uint32_t nu = uint32_t(units.size());
+  std::vector<milzma_result> res(nu);
+  const uint8_t* hout = nullptr;
+  const uint8_t* parts = nullptr;
+  if (nu) {
+    auto fail_all = [&]() {
       for (uint32_t i = 0; i < n; i++) {
         out_reset(&outs[i]);
         infra(ctx, &outs[i]);
       }
       return MILZMA_INFRA_ERROR;
-    }
+    };
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail_all();
+    const size_t parts_bytes = size_t(nu) * kCrcPartsBytes;
+    if (!pin_reserve(ctx, ctx->pin_in, in_total) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
+        !pin_reserve(ctx, ctx->pin_small, parts_bytes) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
+        !dev_reserve(ctx, ctx->out, out_total + 512) || !dev_reserve(ctx, ctx->crc, parts_bytes))
+      return fail_all();
+    uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
+    parallel_for(n, [&](size_t i) {
+      if (planned[i]) memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
+    });
+    if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return fail_all();
+    if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK)
+      return fail_all();
+    // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
+    if (!hip_ok(ctx,
+                launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
+                                 static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, nullptr),
+                "crc kernel launch") ||
+        !hip_ok(ctx, hipMemcpy(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost), "D2H crc parts") ||
+        !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output"))
+      return fail_all();
+    hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+    parts = static_cast<const uint8_t*>(ctx->pin_small.p);
   }
-  // 2. the reference's walk per file; a payload decoded ahead is used only if it is provably what
-  //    an unlimited reader would have produced (clean status, consumed exactly the planned bytes,
-  //    no take() window cut short by the planned end); everything else is decoded on demand.
+  // 3. the reference's walk per file (files in parallel on the host); a payload decoded ahead is used only
+  //    if it is provably what an unlimited reader would have produced (clean status, consumed exactly the
+  //    planned bytes, no take() window cut short by the planned end); everything else is decoded on demand
+  //    (one GPU user at a time).
   std::vector<std::unordered_map<size_t, size_t>> by_off(n);
   for (size_t k = 0; k < refs.size(); k++) by_off[refs[k].file][refs[k].data_off] = k;
-  const PayloadFn live = live_decoder(ctx);
-  for (uint32_t i = 0; i < n; i++) {
+  const PayloadFn live_unlocked = live_decoder(ctx);
+  const PayloadFn live = [&](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return live_unlocked(in, in_len, cap_hint, p);
+  };
+  parallel_for(n, [&](size_t i) {
     const uint8_t* base = ins[i];
     PayloadFn fn = [&, base, i](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
       const auto& m = by_off[i];
-      if (in >= base && in < base + in_lens[i]) {
+      if (hout && in >= base && in < base + in_lens[i]) {
         const auto it = m.find(size_t(in - base));
         if (it != m.end()) {
           const size_t k = it->second;
@@ -1103,15 +1321,17 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
           if (r.status == MILZMA_ST_OK && r.in_consumed == units[k].in_len && !(r.chunks & 0x80000000u) &&
               r.out_len <= units[k].out_cap) {
             p->res = r;
-            p->data = hout.data() + units[k].out_off;
+            p->data = hout + units[k].out_off;
+            crc_fold(parts + k * kCrcPartsBytes, r.out_len, &p->crc32, &p->crc64);
+            p->has_crc = true;
             return true;
           }
         }
       }
       return live(in, in_len, cap_hint, p);
     };
-    xz_walk(ctx, ins[i], in_lens[i], fn, &outs[i]);
-  }
+    xz_walk(ctx, ins[i], in_lens[i], fn, &outs[i], file_out_hint[i]);
+  });
   return MILZMA_OK;
 }
 

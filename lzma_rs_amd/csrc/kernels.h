@@ -29,4 +29,10 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 hipError_t launch_fast(int variant, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
                        const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, hipStream_t stream);
 
+// Partial CRCs (64 chunks per unit) of the units' decoded output; see crc_units.hip.h.
+struct CrcParts;
+constexpr size_t kCrcPartsBytes = 64 * 4 + 64 * 8 + 8;
+hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results,
+                            void* d_parts, hipStream_t stream);
+
 }  // namespace milzma

@@ -4,6 +4,7 @@
 #include "decode_generic.hip.h"
 #include "decode_fast.hip.h"
 #include "decode_fast_asm.hip.h"
+#include "crc_units.hip.h"
 
 namespace milzma {
 
@@ -44,6 +45,15 @@ hipError_t launch_fast(int variant, const milzma_unit* d_units, const uint32_t* 
   else
     hipLaunchKernelGGL(decode_fast_kernel, dim3(n), dim3(kWave), 0, stream, d_units, d_order, n, d_in, d_out,
                        d_results);
+  return hipGetLastError();
+}
+
+hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results,
+                            void* d_parts, hipStream_t stream) {
+  static_assert(sizeof(CrcParts) == kCrcPartsBytes, "CrcParts layout");
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(crc_units_kernel, dim3(n), dim3(kWave), 0, stream, d_units, n, d_out, d_results,
+                     static_cast<CrcParts*>(d_parts));
   return hipGetLastError();
 }
 

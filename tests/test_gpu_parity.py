@@ -440,3 +440,45 @@ def test_decode_units_device_resident(ctx):
     res, _, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
     assert res[0].status == M.ST_OUT_FULL and res[1].status == M.ST_OK
     assert torch.equal(d_out[1000:1 << 18], guard[1000:1 << 18])
+
+
+def test_crc_units_on_device(ctx):
+    # milzma_crc_units: CRC-32 / CRC-64(XZ) of device-resident decoded output (validate_block_check,
+    # src/decode/xz.rs:292-333) against zlib and the oracle, for lengths around the 64-chunk split and
+    # for unaligned output slices
+    import torch
+    import zlib
+    rng = random.Random(8)
+    lens = [0, 1, 2, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 4097, 65536, 70001, (1 << 20) + 3]
+    plains = [bytes(rng.getrandbits(8) for _ in range(min(n, 5000))) * (n // 5000 + 1) for n in lens]
+    plains = [p[:n] for p, n in zip(plains, lens)]
+    comps = [E.dumb_encode(p, unpacked_size=len(p)) if len(p) < 3000 else W.compress_alone(p, dict_size=65536)
+             for p in plains]
+    comps = [c[:5] + struct.pack("<Q", len(p)) + c[13:] for c, p in zip(comps, plains)]
+    n = len(comps)
+    units = (M.Unit * n)()
+    in_off, out_off, blobs = 0, 0, []
+    for i, c in enumerate(comps):
+        u, hl = M.lzma_read_header(c)
+        payload = c[hl:]
+        u.in_off, u.in_len = in_off, len(payload)
+        out_off += 7 if i % 2 else 0  # odd units: unaligned slices (the kernel's byte-wise path)
+        u.out_off, u.out_cap = out_off, len(plains[i]) + 32
+        units[i] = u
+        blobs.append(payload + bytes((-len(payload)) % 256))
+        in_off += len(blobs[-1])
+        out_off = (out_off + len(plains[i]) + 32 + 255) & ~255
+    d_in = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(out_off + 256, dtype=torch.uint8, device="cuda")
+    res, _, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
+    c32, c64 = ctx.crc_units(units, res, d_out.data_ptr(), 0)
+    for i in range(n):
+        assert res[i].status == M.ST_OK and res[i].out_len == len(plains[i]), (i, res[i].status)
+        assert c32[i] == zlib.crc32(plains[i]), (i, lens[i])
+        assert c64[i] == orc.crc64(plains[i]), (i, lens[i])
+    # a failed unit reports 0
+    units[3].out_cap = 4
+    res, _, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
+    c32, c64 = ctx.crc_units(units, res, d_out.data_ptr(), 0)
+    assert res[3].status == M.ST_OUT_FULL and c32[3] == 0 and c64[3] == 0
+    assert c32[4] == zlib.crc32(plains[4])
