@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""configs[4] of BASELINE.json as a timing probe (not a bench.py line): N .xz files of 4 MiB
-(text | 200 KB random | text; 1 MiB blocks; CRC64) through milzma_xz_decompress_batch, host buffers in and out.
-Usage: python experiments/xz_batch_bench.py [files=1024] [distinct=32]"""
+"""The whole-file batch entry points as timing probes (not bench.py lines), host buffers in and out:
+  xz   (default): configs[4] of BASELINE.json, N .xz files of 4 MiB (text | 200 KB random | text; 1 MiB blocks;
+                  CRC64) through milzma_xz_decompress_batch
+  lzma:           configs[1] through milzma_lzma_decompress_batch, N .lzma files of 1 MiB
+Usage: python experiments/batch_api_bench.py [files=1024] [distinct=32] [xz|lzma]"""
 import ctypes
 import os
 import sys
@@ -16,9 +18,13 @@ from lzma_rs_amd import workloads as W  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+mode = sys.argv[3] if len(sys.argv) > 3 else "xz"
 
 
 def one(i):
+    if mode == "lzma":
+        plain = W.make_plain("text", 1 << 20, seed=100 + i)
+        return W.compress_alone(plain, dict_size=65536, known_size=True), plain
     half = (4 * 1048576 - 200_000) // 2
     plain = W.make_plain("text", half, seed=100 + i) + W.make_plain("random", 200_000, seed=200 + i) + \
         W.make_plain("text", 4 * 1048576 - 200_000 - half, seed=300 + i)
@@ -38,7 +44,10 @@ lens = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
 for rep in range(2):
     outs = (M._COutput * n)()
     t0 = time.time()
-    lib.milzma_xz_decompress_batch(ctx._h, n, ptrs, lens, outs)
+    if mode == "lzma":
+        lib.milzma_lzma_decompress_batch(ctx._h, n, ptrs, lens, None, outs)
+    else:
+        lib.milzma_xz_decompress_batch(ctx._h, n, ptrs, lens, outs)
     dt = time.time() - t0
     total = sum(outs[i].len for i in range(n))
     ok = sum(1 for i in range(n) if outs[i].kind == 0)

@@ -805,28 +805,40 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     owner.push_back(i);
   }
   if (units.empty()) return MILZMA_OK;
-  std::vector<uint8_t> hin(in_total), hout(out_total);
-  for (size_t k = 0; k < units.size(); k++)
-    memcpy(hin.data() + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+  // page-locked staging (PCIe at link speed), filled and emptied by several host threads
   std::vector<milzma_result> res(units.size());
-  if (milzma_decode_units_host(ctx, units.data(), uint32_t(units.size()), hin.data(), in_total, hout.data(), out_total,
-                               res.data()) != MILZMA_OK) {
+  auto fail_all = [&]() {
     for (uint32_t i : owner) infra(ctx, &outs[i]);
     return MILZMA_INFRA_ERROR;
-  }
+  };
+  if (!ctx) return fail_all();
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !pin_reserve(ctx, ctx->pin_in, in_total) ||
+      !pin_reserve(ctx, ctx->pin_out, out_total) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
+      !dev_reserve(ctx, ctx->out, out_total + 512))
+    return fail_all();
+  uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
+  const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+  parallel_for(units.size(), [&](size_t k) {
+    memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+  });
+  if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input") ||
+      milzma_decode_units(ctx, units.data(), uint32_t(units.size()), ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK ||
+      !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output"))
+    return fail_all();
   const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
+  parallel_for(units.size(), [&](size_t k) {
+    if (res[k].status != MILZMA_ST_OUT_FULL)
+      finish_stream(res[k], kind, hout + units[k].out_off, size_t(units[k].out_cap), hdr[owner[k]], &outs[owner[k]]);
+  });
   for (size_t k = 0; k < units.size(); k++) {
     const uint32_t i = owner[k];
-    if (res[k].status == MILZMA_ST_OUT_FULL) {  // guessed slice too small: redo alone with growth
-      SingleDecode sd;
-      if (!decode_single(ctx, units[k], ins[i] + hdr[i], size_t(units[k].in_len), size_t(units[k].out_cap) * 4, &sd)) {
-        infra(ctx, &outs[i]);
-        continue;
-      }
-      finish_stream(sd.res, kind, sd.out.data(), sd.out.size(), hdr[i], &outs[i]);
-    } else {
-      finish_stream(res[k], kind, hout.data() + units[k].out_off, size_t(units[k].out_cap), hdr[i], &outs[i]);
+    if (res[k].status != MILZMA_ST_OUT_FULL) continue;
+    SingleDecode sd;  // guessed slice too small: redo alone with growth
+    if (!decode_single(ctx, units[k], ins[i] + hdr[i], size_t(units[k].in_len), size_t(units[k].out_cap) * 4, &sd)) {
+      infra(ctx, &outs[i]);
+      continue;
     }
+    finish_stream(sd.res, kind, sd.out.data(), sd.out.size(), hdr[i], &outs[i]);
   }
   return MILZMA_OK;
 }
