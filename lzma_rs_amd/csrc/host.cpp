@@ -806,7 +806,6 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   }
   if (units.empty()) return MILZMA_OK;
   // page-locked staging (PCIe at link speed), filled and emptied by several host threads
-  std::vector<milzma_result> res(units.size());
   auto fail_all = [&]() {
     for (uint32_t i : owner) infra(ctx, &outs[i]);
     return MILZMA_INFRA_ERROR;
@@ -817,28 +816,48 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       !dev_reserve(ctx, ctx->out, out_total + 512))
     return fail_all();
   uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-  const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
   parallel_for(units.size(), [&](size_t k) {
     memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
   });
-  if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input") ||
-      milzma_decode_units(ctx, units.data(), uint32_t(units.size()), ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK ||
-      !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output"))
-    return fail_all();
+  if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return fail_all();
   const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
-  parallel_for(units.size(), [&](size_t k) {
-    if (res[k].status != MILZMA_ST_OUT_FULL)
-      finish_stream(res[k], kind, hout + units[k].out_off, size_t(units[k].out_cap), hdr[owner[k]], &outs[owner[k]]);
-  });
-  for (size_t k = 0; k < units.size(); k++) {
-    const uint32_t i = owner[k];
-    if (res[k].status != MILZMA_ST_OUT_FULL) continue;
-    SingleDecode sd;  // guessed slice too small: redo alone with growth
-    if (!decode_single(ctx, units[k], ins[i] + hdr[i], size_t(units[k].in_len), size_t(units[k].out_cap) * 4, &sd)) {
-      infra(ctx, &outs[i]);
-      continue;
+  // Rounds: units whose guessed output slice was too small (unknown-size streams) run again, together,
+  // with four times the room; the input stays on the device.
+  std::vector<uint32_t> todo(units.size());
+  for (size_t k = 0; k < units.size(); k++) todo[k] = uint32_t(k);
+  while (!todo.empty()) {
+    std::vector<milzma_unit> sub(todo.size());
+    size_t out_bytes = 0;
+    for (size_t j = 0; j < todo.size(); j++) {
+      sub[j] = units[todo[j]];
+      sub[j].out_off = out_bytes;
+      out_bytes += size_t(sub[j].out_cap);
     }
-    finish_stream(sd.res, kind, sd.out.data(), sd.out.size(), hdr[i], &outs[i]);
+    std::vector<milzma_result> r(sub.size());
+    if (!pin_reserve(ctx, ctx->pin_out, out_bytes) || !dev_reserve(ctx, ctx->out, out_bytes + 512) ||
+        milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), nullptr) != MILZMA_OK ||
+        !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_bytes, hipMemcpyDeviceToHost), "D2H output")) {
+      for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
+      return MILZMA_INFRA_ERROR;
+    }
+    const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+    std::vector<uint8_t> again(sub.size(), 0);
+    parallel_for(sub.size(), [&](size_t j) {
+      if (r[j].status == MILZMA_ST_OUT_FULL && sub[j].out_cap < MILZMA_MAX_UNIT_BYTES) {
+        again[j] = 1;
+        return;
+      }
+      const uint32_t i = owner[todo[j]];
+      finish_stream(r[j], kind, hout + sub[j].out_off, size_t(sub[j].out_cap), hdr[i], &outs[i]);
+    });
+    std::vector<uint32_t> next;
+    for (size_t j = 0; j < sub.size(); j++)
+      if (again[j]) {
+        milzma_unit& u = units[todo[j]];
+        u.out_cap = std::min<uint64_t>(round_up(size_t(u.out_cap) * 4, 256), MILZMA_MAX_UNIT_BYTES);
+        next.push_back(todo[j]);
+      }
+    todo.swap(next);
   }
   return MILZMA_OK;
 }

@@ -334,6 +334,22 @@ def test_xz_multiblock_and_checks(ctx):
     assert ctx.xz(cases[0]).data == plain
 
 
+def test_batch_grows_output_for_unknown_sizes(ctx):
+    # end-marker streams give no size up front: the batch guesses an output slice, and the streams that
+    # overflow it (here: 300 KB of zeros in ~100 bytes) are decoded again, together, with more room
+    plains = [W.make_plain("zeros", 300_000 + 1000 * i, seed=i) for i in range(12)] + \
+             [W.make_plain("repeat", 200_000, seed=50), W.make_plain("text", 100_000, seed=51)]
+    comps = [W.compress_alone(p, dict_size=65536, known_size=False) for p in plains]
+    for comp, plain, d in zip(comps, plains, ctx.lzma_batch(comps)):
+        assert d.ok and d.data == plain
+        same(d, orc.lzma_decompress(comp))
+    raw = [lzma.compress(p, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 65536}])
+           for p in plains[:6]]
+    for comp, plain, d in zip(raw, plains, ctx.lzma2_batch(raw)):
+        assert d.ok and d.data == plain
+        same(d, orc.lzma2_decompress(comp))
+
+
 def test_truncated_at_every_length(ctx):
     # the reader hits EOF at every byte position (inside every kind of symbol, across the 64-byte input
     # window refills): same error, same bytes delivered, same reader position as the reference
