@@ -477,11 +477,12 @@ def test_crc_units_on_device(ctx):
     for i, c in enumerate(comps):
         u, hl = M.lzma_read_header(c)
         payload = c[hl:]
-        u.in_off, u.in_len = in_off, len(payload)
-        out_off += 7 if i % 2 else 0  # odd units: unaligned slices (the kernel's byte-wise path)
+        skew = (1, 3, 5, 63)[i % 4] if i % 2 else 0  # odd units: unaligned input and output slices
+        u.in_off, u.in_len = in_off + skew, len(payload)
+        out_off += 7 if i % 2 else 0                 # (the CRC kernel's byte-wise path)
         u.out_off, u.out_cap = out_off, len(plains[i]) + 32
         units[i] = u
-        blobs.append(payload + bytes((-len(payload)) % 256))
+        blobs.append(bytes(skew) + payload + bytes((-(len(payload) + skew)) % 256))
         in_off += len(blobs[-1])
         out_off = (out_off + len(plains[i]) + 32 + 255) & ~255
     d_in = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
