@@ -41,6 +41,7 @@ LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of t
 STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
 WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
 INTERLEAVE = os.environ.get("MILZMA_GEN_INTERLEAVE", "0") == "1"  # alternate scalar and vector instructions inside a tree decision (measured: -1 %)
+DEFER = os.environ.get("MILZMA_GEN_DEFER", "1") == "1"  # update a tree's probabilities once per tree walk, from the final symbol
 PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
@@ -49,16 +50,18 @@ BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96")
+         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97")
+MPAIR = "s[98:99]"  # a second lane mask
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
-         VLANE192="v101", vb="v102")
+         VLANE192="v101", vb="v102", VSH6="v103", VSH6M1="v104", VSH5="v105", VSH5M1="v106", VSH4="v107",
+         VSH4M1="v108", VLEVEL="v109", va="v110")
 MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
 PS0M2 = "v78"               # PS0 - 2: indexed with len_state + 2
-CLOBBER_S = sorted(set(S.values()) | {"s92", "s93"} | ({"s97", "s98", "s99"} if WAITPROF else set()), key=lambda r: int(r[1:]))  # (+ the refill return address)
+CLOBBER_S = sorted(set(S.values()) | {"s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ the refill return address)
 CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
@@ -251,6 +254,54 @@ class Gen:
         self.post_sym(T, half)
         self.norm()
 
+    def bit_nu(self, T, ln, first=False):
+        """one decision of a tree whose probabilities are updated after the walk (tree_update): 5 scalar +
+        4 vector instructions and a wait state"""
+        e = self.e
+        e("v_lshrrev_b32 {vt}, 11, {range}")
+        e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
+        e("s_nop 0")                                       # gfx940: one wait state between a VALU write and v_readlane
+        e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
+        e("s_sub_u32 {sr1}, {range}, {sb}")
+        e("s_sub_u32 {sc1}, {code}, {sb}")                 # SCC = code < bound  <=>  bit == 0
+        e("s_cselect_b32 {range}, {sb}, {sr1}")
+        e("s_cselect_b32 {code}, {code}, {sc1}")
+        e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
+        self.norm()
+
+    def tree_walk(self, T, nbits, first_lane=None):
+        """nbits decisions down a heap-numbered tree in T (lane = running symbol).  first_lane: constant
+        lane of the root when the symbol starts at 1 (then it is not materialised beforehand)."""
+        for i in range(nbits):
+            first = first_lane is not None and i == 0
+            if DEFER:
+                self.bit_nu(T, first_lane if first else R("sym"), first=first)
+            else:
+                self.bit(T, first_lane if first else R("sym"), first=first)
+
+    def tree_update(self, T, final_level, min_level=None):
+        """The probability updates of a walked tree, all at once: the final symbol (at heap level
+        `final_level`, inverted-bit path) names the visited node of every level (its prefixes) and the bit
+        decided there (the next bit down); lane L was visited iff sym >> (final_level - level(L)) == L.
+        Every visited lane becomes (31 p + K) >> 5, K = 2048 if the bit was 0 (inverted bit 1) else 31.
+        min_level: SGPR; only nodes at that heap level or below it were walked in this table."""
+        if not DEFER:
+            return
+        e = self.e
+        sh, shm1 = {6: ("VSH6", "VSH6M1"), 5: ("VSH5", "VSH5M1"), 4: ("VSH4", "VSH4M1")}[final_level]
+        e("v_lshrrev_b32 {va}, {sh}, {sym}", sh=R(sh))
+        e("v_lshrrev_b32 {vx}, {sh}, {sym}", sh=R(shm1))
+        e("v_cmp_eq_u32 vcc, {va}, {v_lane}")
+        e("v_and_b32 {vx}, 1, {vx}")
+        e("v_mad_u32_u24 {vx}, {vx}, {c2017}, 31")
+        if min_level is not None:
+            e("v_cmp_le_u32 " + MPAIR + ", {m}, {VLEVEL}", m=min_level)
+        e("v_mad_u32_u24 {vt}, {T}, 31, {vx}", T=T)
+        e("v_lshrrev_b32 {vt}, 5, {vt}")
+        if min_level is not None:
+            e("s_and_b64 vcc, vcc, " + MPAIR)
+        e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
+
     def decide(self, T, ln, taken):
         """a decision that ends in a branch: falls through for a 0 bit, jumps to `taken` for a 1 bit.
         The code at `taken` must start with self.taken(T)."""
@@ -309,8 +360,8 @@ class Gen:
         choice, choice2 = str(48 + 2 * which), str(49 + 2 * which)
         self.decide(R("m_ismatch"), choice, w + "_nlow")
         self.e("s_add_u32 {sym}, {ps}, 4")
-        for _ in range(3):
-            self.bit(R(p + "_low"), R("sym"))
+        self.tree_walk(R(p + "_low"), 3)
+        self.tree_update(R(p + "_low"), 5)
         self.e("s_and_b32 {t0}, {sym}, 7")                # length = 2 + path = 9 - inverted path
         self.e("s_sub_u32 {mlen}, 9, {t0}")
         self.lab(done)                                    # the common (short) lengths fall through
@@ -319,17 +370,16 @@ class Gen:
             self.taken(R("m_ismatch"))
             self.decide(R("m_ismatch"), choice2, w + "_high")
             self.e("s_add_u32 {sym}, {ps}, 4")
-            for _ in range(3):
-                self.bit(R(p + "_mid"), R("sym"))
+            self.tree_walk(R(p + "_mid"), 3)
+            self.tree_update(R(p + "_mid"), 5)
             self.e("s_and_b32 {t0}, {sym}, 7")            # length = 10 + path
             self.e("s_sub_u32 {mlen}, 17, {t0}")
             self.e("s_branch " + self.L(done))
             # high: tree of 8, nodes 1..63 in h0, 64..127 in h1, 128..191 in h2, 192..255 in h3
             self.lab(w + "_high")
             self.taken(R("m_ismatch"))
-            self.bit(R(p + "_h0"), "1", first=True)
-            for _ in range(5):
-                self.bit(R(p + "_h0"), R("sym"))
+            self.tree_walk(R(p + "_h0"), 6, first_lane="1")
+            self.tree_update(R(p + "_h0"), 6)
             self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
             self.e("s_bitcmp1_b32 {sym}, 6")
             self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
@@ -448,6 +498,15 @@ class Gen:
         e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
         e("s_movk_i32 {c2017}, 2017")
         e("s_movk_i32 {c2048}, 0x800")
+        if DEFER:                                            # per-lane heap level and the shifts tree_update uses
+            e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
+            e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
+            e("v_sub_u32 {VSH6}, 6, {VLEVEL}")
+            e("v_sub_u32 {VSH6M1}, 5, {VLEVEL}")
+            e("v_sub_u32 {VSH5}, 5, {VLEVEL}")
+            e("v_sub_u32 {VSH5M1}, 4, {VLEVEL}")
+            e("v_sub_u32 {VSH4}, 4, {VLEVEL}")
+            e("v_sub_u32 {VSH4M1}, 3, {VLEVEL}")
         # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
         # prev at hand: a literal here is a plain one) and "M" after a match (state >= 7: a literal here is
         # a matched one and first completes the pending match).
@@ -462,10 +521,17 @@ class Gen:
         self.literal_row("L")
         e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
         e("s_max_i32 {state}, {state}, 0")
-        self.bit(R("u0"), "1", first=True)
-        for i in range(1, 6):       # nodes 1..63 -> u0
-            lab("plain%d" % i)
-            self.bit(R("u0"), R("sym"))
+        if DEFER:
+            e("s_mov_b32 {pl0}, 0")                          # every level of u0 is walked here
+        for i in range(6):          # nodes 1..63 -> u0
+            if i:
+                lab("plain%d" % i)
+            first = i == 0
+            if DEFER:
+                self.bit_nu(R("u0"), "1" if first else R("sym"), first=first)
+            else:
+                self.bit(R("u0"), "1" if first else R("sym"), first=first)
+        self.tree_update(R("u0"), 6, min_level=R("pl0"))
         lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
         self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
         lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
@@ -532,6 +598,8 @@ class Gen:
                     e(acc)
                     self.post_known(T, m != 0, half=m)
                     e("ds_write_b128 {VA}, " + MROW)
+                    if DEFER and i + 1 < 6:
+                        e("s_mov_b32 {pl0}, %d" % (i + 1))
                     self.norm(to="plain%d" % (i + 1))
                 if i < 6:
                     e("s_bitcmp1_b32 {mb}, %d" % (7 - (i + 1)))   # the next match bit picks the sub-table
@@ -586,9 +654,8 @@ class Gen:
         e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
         e("v_mov_b32 {VPS}, " + PS0M2)
         e("s_set_gpr_idx_off")
-        self.bit(V["VPS"], "1", first=True)
-        for _ in range(5):
-            self.bit(V["VPS"], R("sym"))
+        self.tree_walk(V["VPS"], 6, first_lane="1")
+        self.tree_update(V["VPS"], 6)
         e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
         e("v_mov_b32 " + PS0M2 + ", {VPS}")
         e("s_set_gpr_idx_off")
@@ -638,9 +705,8 @@ class Gen:
         e("s_cbranch_scc0 " + L("direct_done"))
         self.direct_bit(R("t4"))
         lab("direct_done")
-        self.bit(R("m_align"), "1", first=True)
-        for _ in range(3):
-            self.bit(R("m_align"), R("sym"))
+        self.tree_walk(R("m_align"), 4, first_lane="1")
+        self.tree_update(R("m_align"), 4)
         e("s_lshl_b32 {t4}, {t4}, 4")
         e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
         e("s_brev_b32 {t3}, {t3}")                           # a'
