@@ -260,7 +260,7 @@ class Gen:
         e = self.e
         e("v_lshrrev_b32 {vt}, 11, {range}")
         e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
-        e("s_nop 0")                                       # gfx940: one wait state between a VALU write and v_readlane
+        e("s_nop 0")  # gfx940: one wait state between a VALU write and the v_readlane of it (measured: without it every stream decodes wrongly)
         e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
         e("s_sub_u32 {sr1}, {range}, {sb}")
         e("s_sub_u32 {sc1}, {code}, {sb}")                 # SCC = code < bound  <=>  bit == 0
