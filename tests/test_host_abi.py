@@ -124,3 +124,39 @@ def test_generated_asm_loop_is_current(tmp_path):
     subprocess.run([sys.executable, str(scratch / "gen_fast_loop.py")], check=True, env=env, stdout=subprocess.DEVNULL)
     with open(inc) as a, open(tmp_path / "lzma_rs_amd" / "csrc" / "fast_loop_asm.inc") as b:
         assert a.read() == b.read()
+
+
+def test_asm_loop_wait_states():
+    """gfx940-family hazards hipcc would pad for but inline asm must respect itself (both measured to matter or
+    listed for the family): a VALU write of a VGPR needs one wait state before a v_readlane of it; a VALU write
+    of VCC needs two before a VALU read of VCC.  Straight-line check over the generated text (labels and
+    branches end a run: a taken branch is more than two wait states)."""
+    inc = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "fast_loop_asm.inc")).read()
+    runs = re.findall(r'#define MILZMA_FAST_LOOP_TEXT_\w+ \\\n((?:  ".*" \\\n)+)', inc)
+    assert len(runs) == 2
+    checked = 0
+    for text in runs:
+        lines = [m for m in re.findall(r'"([^"]*)\\n\\t"', text)]
+        prev = []  # (dest, writes_vcc, is_valu) of the last instructions of the current straight-line run
+        for l in lines:
+            l = l.strip()
+            if l.endswith(":") or l.startswith("s_branch") or l.startswith("s_setpc") or l.startswith("s_call"):
+                prev = []
+                continue
+            ops = l.replace(",", " ").split()
+            op, args = ops[0], ops[1:]
+            if op == "v_readlane_b32":
+                src = args[1]
+                assert not (prev and prev[-1][2] and prev[-1][0] == src), "v_readlane right after the VALU write of %s" % src
+                checked += 1
+            reads_vcc = op.startswith("v_") and "vcc" in args[1:] and not op.startswith("v_cmp")
+            if reads_vcc:
+                for back in prev[-2:]:
+                    assert not back[1], "VALU read of vcc %d instruction(s) after its VALU write: %s" % (1, l)
+                checked += 1
+            is_valu = op.startswith("v_")
+            writes_vcc = op.startswith("v_cmp") and args[0] == "vcc"
+            prev.append((args[0] if args else "", writes_vcc, is_valu))
+            if op.startswith("s_cbranch"):
+                pass  # the fall-through continues the run
+    assert checked > 400
