@@ -198,9 +198,10 @@ def main():
     D.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctx = M.Context(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (== local_rank on a node with one GPU per rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctx = M.Context(dev_index)
     # tile the distinct streams over the n slots (each slot still reads its own copy from HBM)
     units = (M.Unit * n)()
     reps = (n + distinct - 1) // distinct

@@ -25,8 +25,8 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # MILZMA_DIST_BACKEND=gloo: dry runs of the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get("MILZMA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -64,6 +64,8 @@ def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (the step time every rank must agree on)."""
     if not dist.is_initialized():
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -72,6 +74,8 @@ def max_over_ranks(value, device=None):
 def sum_over_ranks(value, device=None):
     if not dist.is_initialized():
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
