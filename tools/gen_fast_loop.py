@@ -42,6 +42,7 @@ STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / m
 WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
 INTERLEAVE = os.environ.get("MILZMA_GEN_INTERLEAVE", "0") == "1"  # alternate scalar and vector instructions inside a tree decision (measured: -1 %)
 DEFER = os.environ.get("MILZMA_GEN_DEFER", "1") == "1"  # update a tree's probabilities once per tree walk, from the final symbol
+JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"  # enter the chain of direct bits with a computed jump instead of looping
 PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
@@ -52,6 +53,7 @@ S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78"
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
          c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97")
 MPAIR = "s[98:99]"  # a second lane mask
+JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
@@ -72,8 +74,8 @@ OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
                "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val"]
-OPS_IN_S = ["out_lim", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc", "out_rsrc",
-            "ldsbase"]
+OPS_IN_S = ["out_lim", "safe_len", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
+            "out_rsrc", "ldsbase"]
 OPS_IN_V = ["v_lane"]
 
 
@@ -323,7 +325,7 @@ class Gen:
         self.norm()
 
     # ---- pending short match ---------------------------------------------------------------------------
-    def finish_pending(self, have_t6=False, prof=None):
+    def finish_pending(self, have_t6=False, prof=None, extract=True):
         if WAITPROF and prof:
             self.e("s_memtime s[98:99]")
             self.e("s_waitcnt lgkmcnt(0)")
@@ -339,10 +341,13 @@ class Gen:
         self.e("s_waitcnt vmcnt(0)")
         self.e("v_cmp_gt_u32 vcc, {pend_n}, {v_lane}")
         self.e("v_add_u32 {VT0}, {pend_pos}, {v_lane}")
-        if not have_t6:
-            self.e("s_add_u32 {t6}, {pend_n}, -1")
-        self.e("v_readlane_b32 {prev}, {pend_val}, {t6}")
-        self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
+        if extract:
+            if not have_t6:
+                self.e("s_add_u32 {t6}, {pend_n}, -1")
+            self.e("v_readlane_b32 {prev}, {pend_val}, {t6}")
+            self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
+        else:                                              # (keeps the v_cmp two instructions away from the v_cndmask)
+            self.e("s_nop 0")
         self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
@@ -674,36 +679,50 @@ class Gen:
         e("s_lshl_b32 {t2}, {t2}, {t1}")
         e("s_add_u32 {t3}, {t1}, -4")                       # count
         e("s_mov_b32 {t4}, 0")
-        lab("direct4")
-        e("s_cmp_lt_u32 {t3}, 4")
-        e("s_cbranch_scc1 " + L("direct_tail"))
-        for _ in range(4):
+        if JUMP and not PREFETCH:
+            # 26 identical blocks (the most a distance can have), entered so that exactly `count` of them run:
+            # one computed jump instead of a loop with a test per group of four and a tail
+            e("s_getpc_b64 " + JPAIR)
+            lab("direct_pc")
+            e("s_mul_i32 {t5}, {t3}, (" + L("direct_done") + "-" + L("direct_chain") + ")/26")
+            e("s_sub_u32 {t5}, " + L("direct_done") + "-" + L("direct_pc") + ", {t5}")
+            e("s_add_u32 " + JPAIR_LO + ", " + JPAIR_LO + ", {t5}")
+            e("s_addc_u32 " + JPAIR_HI + ", " + JPAIR_HI + ", 0")
+            e("s_setpc_b64 " + JPAIR)
+            lab("direct_chain")
+            for _ in range(26):
+                self.direct_bit(R("t4"))
+        else:
+            lab("direct4")
+            e("s_cmp_lt_u32 {t3}, 4")
+            e("s_cbranch_scc1 " + L("direct_tail"))
+            for _ in range(4):
+                self.direct_bit(R("t4"))
+            e("s_add_u32 {t3}, {t3}, -4")
+            e("s_branch " + L("direct4"))
+            lab("direct_tail")
+            if PREFETCH:
+                # t3 = r direct bits (0..3) and the 4 align bits are still to come: the distance is known to within
+                # 2^(r+4) bytes.  rep0 + 1 lies in (R0 - 2^(r+4), R0] with R0 = t2 - (t4 << (r+4)), so the source starts
+                # in [len - R0, len - R0 + 2^(r+4)): pull those lines towards L2 now with (dummy) scalar loads -- the
+                # copy's vector load, ~100 instructions from here, otherwise pays the full dictionary-read latency.
+                e("s_add_u32 {t5}, {t3}, 4")
+                e("s_lshl_b32 {t5}, {t4}, {t5}")
+                e("s_sub_u32 {t5}, {t2}, {t5}")
+                e("s_sub_u32 {t5}, {len}, {t5}")
+                e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
+                e("s_add_u32 {t6}, {t5}, 64")
+                e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
+                e("s_add_u32 {t6}, {t5}, 0x80")
+                e("s_buffer_load_dword {pf2}, {out_rsrc}, {t6}")
+            e("s_bitcmp1_b32 {t3}, 1")
+            e("s_cbranch_scc0 " + L("direct_t1"))
+            for _ in range(2):
+                self.direct_bit(R("t4"))
+            lab("direct_t1")
+            e("s_bitcmp1_b32 {t3}, 0")
+            e("s_cbranch_scc0 " + L("direct_done"))
             self.direct_bit(R("t4"))
-        e("s_add_u32 {t3}, {t3}, -4")
-        e("s_branch " + L("direct4"))
-        lab("direct_tail")
-        if PREFETCH:
-            # t3 = r direct bits (0..3) and the 4 align bits are still to come: the distance is known to within
-            # 2^(r+4) bytes.  rep0 + 1 lies in (R0 - 2^(r+4), R0] with R0 = t2 - (t4 << (r+4)), so the source starts
-            # in [len - R0, len - R0 + 2^(r+4)): pull those lines towards L2 now with (dummy) scalar loads -- the
-            # copy's vector load, ~100 instructions from here, otherwise pays the full dictionary-read latency.
-            e("s_add_u32 {t5}, {t3}, 4")
-            e("s_lshl_b32 {t5}, {t4}, {t5}")
-            e("s_sub_u32 {t5}, {t2}, {t5}")
-            e("s_sub_u32 {t5}, {len}, {t5}")
-            e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
-            e("s_add_u32 {t6}, {t5}, 64")
-            e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
-            e("s_add_u32 {t6}, {t5}, 0x80")
-            e("s_buffer_load_dword {pf2}, {out_rsrc}, {t6}")
-        e("s_bitcmp1_b32 {t3}, 1")
-        e("s_cbranch_scc0 " + L("direct_t1"))
-        for _ in range(2):
-            self.direct_bit(R("t4"))
-        lab("direct_t1")
-        e("s_bitcmp1_b32 {t3}, 0")
-        e("s_cbranch_scc0 " + L("direct_done"))
-        self.direct_bit(R("t4"))
         lab("direct_done")
         self.tree_walk(R("m_align"), 4, first_lane="1")
         self.tree_update(R("m_align"), 4)
@@ -807,10 +826,9 @@ class Gen:
         e("s_cbranch_scc1 " + L("Xlz_dist_out"))
         e("s_cmpk_ge_u32 {mlen}, 64")
         e("s_cbranch_scc1 " + L("Xlz_slow"))
-        e("s_add_u32 {t2}, {len}, {mlen}")                    # the output resource starts at dict_base: pos = len
-        e("s_cbranch_scc1 " + L("Xlz_slow"))
-        e("s_cmp_gt_u32 {t2}, {out_lim}")
-        e("s_cbranch_scc1 " + L("Xlz_slow"))
+        e("s_cmp_gt_u32 {len}, {safe_len}")                   # within 273 bytes of the output limit: look closer
+        e("s_cbranch_scc1 " + L("Ocopy_limit"))
+        lab("cp_lim_ok")
         e("s_cmp_lg_u32 {pend_n}, 0")
         e("s_cbranch_scc1 " + L("Opend_copy"))
         lab("cp_a")
@@ -841,10 +859,18 @@ class Gen:
             e("v_add_u32 {VT0}, {t2}, {VT2}")
             e("s_branch " + L("cp_b"))
 
+            lab("Ocopy_limit")                                # (the output resource starts at dict_base: pos = len)
+            e("s_add_u32 {t2}, {len}, {mlen}")
+            e("s_cbranch_scc1 " + L("Xlz_slow"))
+            e("s_cmp_gt_u32 {t2}, {out_lim}")
+            e("s_cbranch_scc1 " + L("Xlz_slow"))
+            e("s_branch " + L("cp_lim_ok"))
             lab("Opend_copy")
             e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
             e("s_cbranch_scc1 " + L("Opend_clear"))
-            self.finish_pending(prof="c")
+            # (prev / mb are not taken from it: a match follows, and whatever symbol comes after that gets them
+            #  from that match's bytes)
+            self.finish_pending(prof="c", extract=False)
             e("s_branch " + L("cp_a"))
             lab("Opend_clear")
             e("s_mov_b32 {pend_n}, 0")
