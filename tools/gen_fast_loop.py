@@ -51,7 +51,7 @@ BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97")
+         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s101")
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 RET = "s[92:93]"  # return address of the window refill subroutine
@@ -451,15 +451,20 @@ class Gen:
         """top of a symbol (lzma.rs:435-459) up to the is_match decision; falls through for a literal"""
         e, lab, L = self.e, self.lab, self.L
         lab("top" + tag)
-        e("s_cmp_ge_u32 {len}, {target}")
-        e("s_cbranch_scc1 " + L("Xdone_size"))
-        e("s_cmp_eq_u32 {off}, {lim}")                   # reader at EOF: the stream may be finished
-        e("s_cbranch_scc1 " + L("Ofin_check" + tag))
+        # one test for "the size is reached" and "the reader may be at EOF": gtop = target while more than a
+        # window of input is left (then off < lim for sure), 0 in the last window (every symbol looks closer)
+        e("s_cmp_ge_u32 {len}, {gtop}")
+        e("s_cbranch_scc1 " + L("Otop_slow" + tag))
         lab("top2" + tag)
         e("s_and_b32 {ps}, {len}, {pbmask}")
         e("s_lshl2_add_u32 {ln}, {state}, {ps}")
         self.decide(R("m_ismatch"), R("ln"), "match")
         with self.in_cold():
+            lab("Otop_slow" + tag)
+            e("s_cmp_ge_u32 {len}, {target}")
+            e("s_cbranch_scc1 " + L("Xdone_size"))
+            e("s_cmp_eq_u32 {off}, {lim}")                    # reader at EOF: the stream may be finished
+            e("s_cbranch_scc0 " + L("top2" + tag))
             lab("Ofin_check" + tag)                           # unknown size: finished when the reader is at EOF
             e("s_or_b32 {t0}, {code}, {known}")               # and code == 0 (is_finished_ok, rangecoder.rs:48-50)
             e("s_cbranch_scc0 " + L("Xdone_fin"))
@@ -503,6 +508,8 @@ class Gen:
         e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
         e("s_movk_i32 {c2017}, 2017")
         e("s_movk_i32 {c2048}, 0x800")
+        e("s_cmpk_gt_u32 {lim}, 63")
+        e("s_cselect_b32 {gtop}, {target}, 0")
         if DEFER:                                            # per-lane heap level and the shifts tree_update uses
             e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
             e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
@@ -882,6 +889,8 @@ class Gen:
             e("s_add_u32 {wbase}, {wbase}, 64")
             e("s_mov_b32 {off}, 0")
             e("s_sub_u32 {lim}, {lim}, 64")
+            e("s_cmpk_gt_u32 {lim}, 63")
+            e("s_cselect_b32 {gtop}, {target}, 0")
             e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
