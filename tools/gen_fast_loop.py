@@ -46,6 +46,7 @@ JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"  # enter the chain of direc
 PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
+assert not (WAITPROF and PREFETCH), "the wait profile borrows the prefetch registers"
 
 
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
@@ -326,15 +327,15 @@ class Gen:
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False, prof=None, extract=True):
-        if WAITPROF and prof:
-            self.e("s_memtime s[98:99]")
+        if WAITPROF and prof:                              # (uses the prefetch registers: not together with PREFETCH)
+            self.e("s_memtime s[94:95]")
             self.e("s_waitcnt lgkmcnt(0)")
-            self.e("s_mov_b32 s97, s98")
+            self.e("s_mov_b32 s96, s94")
             self.e("s_waitcnt vmcnt(0)")
-            self.e("s_memtime s[98:99]")
+            self.e("s_memtime s[94:95]")
             self.e("s_waitcnt lgkmcnt(0)")
-            self.e("s_sub_u32 s97, s98, s97")
-            self.e("s_add_u32 {w}, {w}, s97", w=R("prof_w" + prof))
+            self.e("s_sub_u32 s96, s94, s96")
+            self.e("s_add_u32 {w}, {w}, s96", w=R("prof_w" + prof))
             self.e("s_add_u32 {n}, {n}, 1", n=R("prof_n" + prof))
         # (gfx940 family: a VALU write of VCC / an SGPR wants 2 wait states before a VALU read of it, hence
         #  the order: the v_cmp that writes vcc is never followed directly by the v_cndmask that reads it)
