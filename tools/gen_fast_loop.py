@@ -14,13 +14,18 @@ end-of-stream marker, the output limit.
 Conventions inside the loop
   * range, code and every piece of LZMA state are SGPRs; the probability model is lane-resident
     (one probability per lane of a VGPR, see decode_fast_asm.hip.h for the layout).
-  * A decision:  v_readlane p; bound = (range >> 11) * p; s_sub code - bound sets SCC = (code < bound)
-    = "bit is 0"; two s_cselect pick range / code.  The owning lane's probability is updated by
-    v_cmp_eq(lane) + v_cndmask, without touching EXEC.
-  * The scalar ALU (one instruction per cycle per CU, shared by the CU's 16 waves) is the binding unit
-    (PMC: 97 % busy), so whatever can be done on the vector ALU is: the update constant comes from the
-    symbol's low bit (v_and / v_mad), the "range < 2^24" test is a v_cmp + s_cbranch_vccnz, and where a
-    decision ends in a branch anyway each side applies the update for the bit value it knows.
+  * A decision: every lane computes the bound of its own probability, (range >> 11) * p (v_lshrrev,
+    v_mul_u32_u24), v_readlane picks the node's; s_sub of code - bound sets SCC = (code < bound) = "bit is 0";
+    two s_cselect pick range / code.  No EXEC manipulation anywhere.
+  * The scalar pipe (one instruction per cycle per CU, shared by the CU's 16 waves) is the binding unit, so
+    whatever can be done on the vector ALU or once instead of per decision is:
+      - the probabilities of a walked tree are updated once per walk (tree_update): the final symbol names the
+        visited node of every level and the bit decided there, so every lane can tell from its own index
+        whether it was visited; single decisions update their lane under a v_cmp_eq(lane) / v_cndmask mask,
+        on the side of the branch that knows the bit where there is one;
+      - the "range < 2^24" test is a v_cmp + s_cbranch_vccnz;
+      - rare conditions share a guard: one compare at the top of a symbol for "size reached" / "reader may be at
+        EOF", one per match for "near the output limit".
   * Symbols are accumulated with s_addc, i.e. with INVERTED bits (SCC = bit is 0).  Tree nodes are
     therefore stored at the lane of the inverted path, which is a permutation inside each tree level
     and costs nothing (all probabilities start equal); decoded values are un-inverted once per symbol.
@@ -31,6 +36,9 @@ Conventions inside the loop
     the CU compete for -- so rare work is always moved behind a branch.
   * Input: a 64-byte window, one byte per lane (winb), the next one prefetched (winb_next); `off` is
     the lane of the next byte, `lim` the value of `off` at which the decoder's reader is at EOF.
+  * gfx940-family wait states hipcc would insert but inline asm must provide itself: one between a VALU write
+    of a VGPR and a v_readlane of it (measured: without it every stream decodes wrongly), two between a VALU
+    write of VCC and a VALU read of it (tests/test_host_abi.py lints the generated text for both).
 """
 import os
 import re
