@@ -60,7 +60,7 @@ assert not (WAITPROF and PREFETCH), "the wait profile borrows the prefetch regis
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s101")
+         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s101", gdist="s100")
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 RET = "s[92:93]"  # return address of the window refill subroutine
@@ -519,6 +519,7 @@ class Gen:
         e("s_movk_i32 {c2048}, 0x800")
         e("s_cmpk_gt_u32 {lim}, 63")
         e("s_cselect_b32 {gtop}, {target}, 0")
+        e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
         if DEFER:                                            # per-lane heap level and the shifts tree_update uses
             e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
             e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
@@ -542,17 +543,20 @@ class Gen:
         self.literal_row("L")
         e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
         e("s_max_i32 {state}, {state}, 0")
-        if DEFER:
-            e("s_mov_b32 {pl0}, 0")                          # every level of u0 is walked here
-        for i in range(6):          # nodes 1..63 -> u0
-            if i:
-                lab("plain%d" % i)
-            first = i == 0
-            if DEFER:
-                self.bit_nu(R("u0"), "1" if first else R("sym"), first=first)
-            else:
-                self.bit(R("u0"), "1" if first else R("sym"), first=first)
-        self.tree_update(R("u0"), 6, min_level=R("pl0"))
+        if DEFER:                   # nodes 1..63 -> u0
+            self.tree_walk(R("u0"), 6, first_lane="1")
+            self.tree_update(R("u0"), 6)
+            with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
+                for i in range(1, 6):   # only the levels from pl0 on were walked in u0
+                    lab("plain%d" % i)
+                    self.bit_nu(R("u0"), R("sym"))
+                self.tree_update(R("u0"), 6, min_level=R("pl0"))
+                e("s_branch " + L("plain6"))
+        else:
+            for i in range(6):
+                if i:
+                    lab("plain%d" % i)
+                self.bit(R("u0"), "1" if i == 0 else R("sym"), first=i == 0)
         lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
         self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
         lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
@@ -836,10 +840,9 @@ class Gen:
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
         lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
         e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cmp_gt_u32 {t0}, {dict_size}")
-        e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
-        e("s_cmp_gt_u32 {t0}, {len}")
-        e("s_cbranch_scc1 " + L("Xlz_dist_out"))
+        e("s_cmp_gt_u32 {t0}, {gdist}")                       # gdist <= min(len, dict_size): beyond it, look closer
+        e("s_cbranch_scc1 " + L("Ocopy_dist"))
+        lab("cp_dist_ok")
         e("s_cmpk_ge_u32 {mlen}, 64")
         e("s_cbranch_scc1 " + L("Xlz_slow"))
         e("s_cmp_gt_u32 {len}, {safe_len}")                   # within 273 bytes of the output limit: look closer
@@ -875,6 +878,12 @@ class Gen:
             e("v_add_u32 {VT0}, {t2}, {VT2}")
             e("s_branch " + L("cp_b"))
 
+            lab("Ocopy_dist")                                 # append_lz's two distance errors, in the reference's order
+            e("s_cmp_gt_u32 {t0}, {dict_size}")
+            e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
+            e("s_cmp_gt_u32 {t0}, {len}")
+            e("s_cbranch_scc1 " + L("Xlz_dist_out"))
+            e("s_branch " + L("cp_dist_ok"))
             lab("Ocopy_limit")                                # (the output resource starts at dict_base: pos = len)
             e("s_add_u32 {t2}, {len}, {mlen}")
             e("s_cbranch_scc1 " + L("Xlz_slow"))
@@ -900,6 +909,7 @@ class Gen:
             e("s_sub_u32 {lim}, {lim}, 64")
             e("s_cmpk_gt_u32 {lim}, 63")
             e("s_cselect_b32 {gtop}, {target}, 0")
+            e("s_min_u32 {gdist}, {len}, {dict_size}")
             e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
