@@ -60,7 +60,7 @@ assert not (WAITPROF and PREFETCH), "the wait profile borrows the prefetch regis
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s101", gdist="s100")
+         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 RET = "s[92:93]"  # return address of the window refill subroutine
