@@ -55,12 +55,22 @@ PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads tha
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
 assert not (WAITPROF and PREFETCH), "the wait profile borrows the prefetch registers"
+# sensitivity probes (tuning only): k dead scalar / vector / never-taken-branch instructions per adaptive decision
+PAD_S = int(os.environ.get("MILZMA_GEN_PAD_S", "0"))
+PAD_V = int(os.environ.get("MILZMA_GEN_PAD_V", "0"))
+PAD_B = int(os.environ.get("MILZMA_GEN_PAD_B", "0"))
+# wave priority rotation: the SIMD's issue arbiter serves the oldest wave first, which (measured, per-wave clocks) lets the
+# first-dispatched wave of a SIMD run at lone-wave speed (222 ms) while the youngest needs 324 ms -- and the kernel ends
+# with the youngest.  PRIO = k > 0: every window refill sets s_setprio ((len >> k) + wave slot) & 3, so that the four waves
+# of a SIMD take turns at every priority and finish together.  PRIO = -1: static priority = wave slot (diagnostic).
+PRIO = int(os.environ.get("MILZMA_GEN_PRIO", "12"))
+NORM_S = os.environ.get("MILZMA_GEN_NORM_S", "0") == "1"  # the "range < 2^24" test on the scalar ALU instead of the vector ALU
 
 
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
+         c2017="s90", c2048="s91", pad="s69", prioph="s68", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 RET = "s[92:93]"  # return address of the window refill subroutine
@@ -68,6 +78,8 @@ V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90"
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
          VLANE192="v101", vb="v102", VSH6="v103", VSH6M1="v104", VSH5="v105", VSH5M1="v106", VSH4="v107",
          VSH4M1="v108", VLEVEL="v109", va="v110")
+if PAD_V:
+    V["vpad"] = "v111"
 MROW = "v[84:87]"
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
 PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
@@ -140,8 +152,12 @@ class Gen:
         """RangeDecoder::normalize (rangecoder.rs:59-69) as a check + out-of-line stub.
         `to`: label to continue at (default: fall through)."""
         k = self.new("N")
-        self.e("v_cmp_lt_u32 vcc, {range}, {VKTOP}")     # all lanes agree
-        self.e("s_cbranch_vccnz " + self.L(k))
+        if NORM_S:
+            self.e("s_cmp_lt_u32 {range}, 0x1000000")
+            self.e("s_cbranch_scc1 " + self.L(k))
+        else:
+            self.e("v_cmp_lt_u32 vcc, {range}, {VKTOP}")     # all lanes agree
+            self.e("s_cbranch_vccnz " + self.L(k))
         if to is None:
             ret = self.new("R")
             self.lab(ret)
@@ -162,10 +178,19 @@ class Gen:
             self.e("s_call_b64 " + RET + ", " + self.L("refill"))
             self.e("s_branch " + self.L(ret))
 
+    def pad(self):
+        for _ in range(PAD_S):
+            self.e("s_mov_b32 {pad}, 0")
+        for _ in range(PAD_V):
+            self.e("v_mov_b32 {vpad}, 0")
+        for _ in range(PAD_B):
+            self.e("s_cbranch_execz " + self.L("finish"))
+
     def core(self, T, ln, half=None, cmp_lane=None):
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
         0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
+        self.pad()
         if BOUND_ON_VALU:
             # every lane computes the bound of its own probability; the one that is needed is read out
             self.e("v_lshrrev_b32 {vt}, 11, {range}")
@@ -269,6 +294,7 @@ class Gen:
         """one decision of a tree whose probabilities are updated after the walk (tree_update): 5 scalar +
         4 vector instructions and a wait state"""
         e = self.e
+        self.pad()
         e("v_lshrrev_b32 {vt}, 11, {range}")
         e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
         e("s_nop 0")  # gfx940: one wait state between a VALU write and the v_readlane of it (measured: without it every stream decodes wrongly)
@@ -360,6 +386,17 @@ class Gen:
         self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
+
+    def set_prio(self, reg, tmp):
+        """s_setprio takes an immediate: a short chain picks the instruction for reg & 3 (clobbers SCC and tmp)"""
+        done = self.new("P")
+        self.e("s_and_b32 {t}, {r}, 3", r=reg, t=tmp)
+        for k in range(3):
+            self.e("s_setprio %d" % k)
+            self.e("s_cmp_eq_u32 {t}, %d" % k, t=tmp)
+            self.e("s_cbranch_scc1 " + self.L(done))
+        self.e("s_setprio 3")
+        self.lab(done)
 
     def exit_with(self, code):
         self.e("s_mov_b32 {exitcode}, %d" % EXIT[code])
@@ -520,6 +557,10 @@ class Gen:
         e("s_cmpk_gt_u32 {lim}, 63")
         e("s_cselect_b32 {gtop}, {target}, 0")
         e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
+        if PRIO:
+            e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD
+            if PRIO < 0:
+                self.set_prio(R("prioph"), R("n0"))
         if DEFER:                                            # per-lane heap level and the shifts tree_update uses
             e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
             e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
@@ -913,6 +954,10 @@ class Gen:
             e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
+            if PRIO > 0:
+                e("s_lshr_b32 {n1}, {len}, %d" % PRIO)       # (n0 / n1: the only temporaries free wherever a refill happens)
+                e("s_add_u32 {n1}, {n1}, {prioph}")
+                self.set_prio(R("n1"), R("n0"))
             e("s_setpc_b64 " + RET)
 
             lab("Omb_fetch")                                  # lzb.last_n(rep0 + 1)
