@@ -15,8 +15,9 @@ import bench  # noqa: E402
 import ctypes  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dict_size = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 16
 distinct = 64
-units_d, blob_d, comp_d, gen_s = bench.build_batch(distinct, 1 << 20, "text", 1 << 16, first_index=0, processes=8)
+units_d, blob_d, comp_d, gen_s = bench.build_batch(distinct, 1 << 20, "text", dict_size, first_index=0, processes=bench.effective_cores())
 ctx = M.Context(0)
 dev = torch.device("cuda", 0)
 units = (M.Unit * n)()
@@ -35,6 +36,6 @@ wm = sum(r.err_a >> 32 for r in res) / n
 nm = sum(r.err_a & 0xFFFFFFFF for r in res) / n
 wc = sum(r.err_b >> 32 for r in res) / n
 nc = sum(r.err_b & 0xFFFFFFFF for r in res) / n
-print("kernel %.1f ms, %d streams" % (ms, n))
+print("kernel %.1f ms, %d streams, dict %d" % (ms, n, dict_size))
 print("matched-literal site: %.0f events/stream, %.0f ticks each (s_memtime, 100 MHz), %.1f ms per stream" % (nm, wm / max(nm, 1), wm / 1e5))
 print("copy site:            %.0f events/stream, %.0f ticks each, %.1f ms per stream" % (nc, wc / max(nc, 1), wc / 1e5))

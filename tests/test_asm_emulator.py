@@ -1,0 +1,73 @@
+"""The generated gfx950 symbol loop (tools/gen_fast_loop.py -> lzma_rs_amd/csrc/fast_loop_asm.inc), executed
+instruction by instruction on the CPU by tools/emu (a functional emulator of the instruction subset the loop
+uses) and compared with the oracle: bytes, final status and reader position.  This is how a generator change
+is checked without a GPU; the `-m gpu` parity tests remain the proof on hardware.  Reference behaviour:
+src/decode/lzma.rs:255-593, src/decode/rangecoder.rs, src/decode/lzbuffer.rs:167-321."""
+import lzma
+import os
+import random
+import struct
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+
+import asmprog  # noqa: E402
+import oracle_py as orc  # noqa: E402
+from lzma_rs_amd import workloads as W  # noqa: E402
+
+
+def _hdr(comp):
+    props = comp[0]
+    ds = struct.unpack("<I", comp[1:5])[0]
+    us = struct.unpack("<Q", comp[5:13])[0]
+    return props % 9, (props // 9) % 5, props // 45, max(ds, 4096), (None if us == 0xFFFFFFFFFFFFFFFF else us)
+
+
+@pytest.fixture(scope="module")
+def loops():
+    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False)}
+    yield m
+    for a in m.values():
+        a.close()
+
+
+def _check(loops, comp, plain):
+    lc, lp, pb, ds, us = _hdr(comp)
+    r = loops[lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
+    ref = orc.lzma_decompress(comp)
+    assert ref.out == plain
+    assert r["status"] == "OK" and r["out"] == plain
+    assert r["in_consumed"] + 13 == ref.in_consumed
+
+
+@pytest.mark.parametrize("kind", ["text", "random", "repeat", "zeros"])
+@pytest.mark.parametrize("known", [True, False])
+def test_emulated_loop_bench_classes(loops, kind, known):
+    for size in (1, 100, 5000, 70000):
+        plain = W.make_plain(kind, size, seed=W.SEED0 ^ size)
+        _check(loops, W.compress_alone(plain, dict_size=65536, known_size=known), plain)
+
+
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (3, 0, 0)])
+def test_emulated_loop_props_and_near_distances(loops, lc, lp, pb):
+    """small dictionary: exercises the reverse-tree distance slots (4..13) and rep matches"""
+    rnd = random.Random(lc * 100 + lp * 10 + pb)
+    plain = W.make_plain("text", 30000, seed=lc * 100 + lp * 10 + pb) + bytes(rnd.randrange(256) for _ in range(3000)) + b"abc" * 5000
+    filt = [{"id": lzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 12}]
+    _check(loops, lzma.compress(plain, format=lzma.FORMAT_ALONE, filters=filt), plain)
+
+
+def test_emulated_loop_truncated_and_oversized_declared(loops):
+    plain = W.make_plain("text", 20000, seed=7)
+    comp = W.compress_alone(plain, dict_size=65536, known_size=True)
+    lc, lp, pb, ds, us = _hdr(comp)
+    r = loops[True].decode_raw(comp[13:len(comp) // 2], lc, lp, pb, ds, us, out_cap=len(plain))
+    ref = orc.lzma_decompress(comp[:len(comp) // 2])
+    assert r["status"] == "INPUT_EOF" and ref.kind != 0
+    assert r["out"][:len(ref.out)] == ref.out          # what the reference flushed is a prefix of what was decoded
+    r = loops[True].decode_raw(comp[13:], lc, lp, pb, ds, us - 5, out_cap=len(plain))
+    assert r["status"] in ("OK", "SIZE_MISMATCH") and r["out"][:us - 5] == plain[:us - 5]

@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Front end of the asm-loop emulator (tools/emu/emu.cpp): turns the text tools/gen_fast_loop.py
+generates into the emulator's pre-parsed program and drives one wavefront through a raw LZMA stream
+the way decode_fast_asm_kernel / AsmDecoder::process (lzma_rs_amd/csrc/decode_fast_asm.hip.h) do.
+
+Test / tuning infrastructure only (tests/test_asm_emulator.py, tools/emu/profile.py): it lets a
+generator change be checked bit-exactly against the oracle on the CPU, and gives exact executed-
+instruction counts per class.  Nothing in the product imports it."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+K_S, K_V, K_I, K_L, K_VCC = 0, 1, 2, 3, 4
+GPR_IDX = {"SRC0": 1, "SRC1": 2, "SRC2": 4, "DST": 8}
+
+ST_OK, ST_INPUT_EOF, ST_RC_INIT = "OK", "INPUT_EOF", "RC_INIT"
+
+
+def _lib():
+    so = os.path.join(HERE, "libasmemu.so")
+    src = os.path.join(HERE, "emu.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", so])
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    L.emu_create.restype = vp
+    L.emu_create.argtypes = [ctypes.c_char_p]
+    L.emu_destroy.argtypes = [vp]
+    L.emu_error.restype = ctypes.c_char_p
+    L.emu_error.argtypes = [vp]
+    L.emu_set_mem.argtypes = [vp, vp, ctypes.c_uint64]
+    L.emu_set_s.argtypes = [vp, ctypes.c_int, ctypes.c_uint32]
+    L.emu_get_s.restype = ctypes.c_uint32
+    L.emu_get_s.argtypes = [vp, ctypes.c_int]
+    L.emu_set_v.argtypes = [vp, ctypes.c_int, vp]
+    L.emu_get_v.argtypes = [vp, ctypes.c_int, vp]
+    L.emu_set_hwreg.argtypes = [vp, ctypes.c_uint32]
+    L.emu_lds_write.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_uint32]
+    L.emu_run.restype = ctypes.c_long
+    L.emu_run.argtypes = [vp, ctypes.c_int, ctypes.c_long]
+    L.emu_counts.argtypes = [vp, vp, vp]
+    L.emu_reset_counts.argtypes = [vp]
+    L.emu_size.restype = ctypes.c_int
+    L.emu_size.argtypes = [vp]
+    return L
+
+
+def split_operands(text):
+    """comma-separated operands; commas inside (...) or [...] do not split"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+class Program:
+    """lines: the generator's instruction / label lines.  regmap: operand name -> 'sN' / 'vN'."""
+
+    def __init__(self, lines, regmap):
+        self.regmap = regmap
+        self.labels = {}
+        self.text = []    # instruction text per index
+        self.region = []  # innermost preceding label per instruction
+        cur = "entry"
+        for ln in lines:
+            s = ln.strip()
+            if not s:
+                continue
+            if s.endswith(":"):
+                name = s[:-1]
+                self.labels[name] = len(self.text)
+                cur = name
+                continue
+            self.text.append(s)
+            self.region.append(cur)
+        self.encoded = [self._encode(i, t) for i, t in enumerate(self.text)]
+
+    def _reg(self, tok):
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            return (K_S, int(m.group(1)))
+        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+        if m:
+            return (K_S, int(m.group(1)))
+        m = re.fullmatch(r"v(\d+)", tok)
+        if m:
+            return (K_V, int(m.group(1)))
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return (K_V, int(m.group(1)))
+        if tok == "vcc":
+            return (K_VCC, 0)
+        if tok == "m0":
+            return (K_S, 124)
+        return None
+
+    def _operand(self, tok):
+        tok = tok.strip()
+        m = re.fullmatch(r"%\[(\w+)\]", tok)
+        if m:
+            tok = self.regmap[m.group(1)]
+        r = self._reg(tok)
+        if r:
+            return r
+        if re.fullmatch(r"-?\d+", tok):
+            return (K_I, int(tok) & 0xFFFFFFFF)
+        if re.fullmatch(r"0x[0-9a-fA-F]+", tok):
+            return (K_I, int(tok, 16) & 0xFFFFFFFF)
+        if re.fullmatch(r"-?\d+\.\d+", tok):
+            return (K_I, struct.unpack("<I", struct.pack("<f", float(tok)))[0])
+        m = re.fullmatch(r"gpr_idx\(([\w,\s]+)\)", tok)
+        if m:
+            return (K_I, sum(GPR_IDX[x.strip()] for x in m.group(1).split(",")))
+        if tok.startswith("hwreg("):
+            return (K_I, 0)
+        if tok in self.labels:
+            return (K_L, self.labels[tok])
+        # label arithmetic: addresses are 4 * instruction index
+        expr = re.sub(r"L\w+%=", lambda mm: str(4 * self.labels[mm.group(0)]), tok)
+        if re.fullmatch(r"[\d\s()+\-*/]+", expr):
+            return (K_I, int(eval(expr.replace("/", "//"))) & 0xFFFFFFFF)
+        raise ValueError("cannot parse operand %r" % tok)
+
+    def _encode(self, idx, text):
+        parts = text.split(None, 1)
+        op = parts[0]
+        ops = split_operands(parts[1]) if len(parts) > 1 else []
+        if op in ("s_waitcnt", "s_nop", "s_sleep", "s_setprio", "s_set_gpr_idx_off"):
+            ops = []
+        if op.startswith("buffer_"):
+            # vdata, vaddr, srsrc, "soffset offen [mods]"
+            last = ops[3].split()
+            assert "offen" in last, text
+            ops = ops[:3] + [last[0]]
+        if op.startswith("ds_"):
+            ops = [o for o in ops if not o.startswith("offset:")] + [o.split(":")[1] for o in ops if o.startswith("offset:")]
+        enc = [self._operand(o) for o in ops]
+        return "%s %d %s" % (op, len(enc), " ".join("%d %d" % e for e in enc))
+
+    def blob(self):
+        return ("\n".join(self.encoded) + "\n").encode()
+
+
+def classify(text):
+    op = text.split()[0]
+    if op in ("s_nop", "s_waitcnt", "s_sleep", "s_setprio"):
+        return "misc"
+    if op.startswith("s_cbranch") or op in ("s_branch", "s_setpc_b64", "s_call_b64"):
+        return "branch"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("buffer_"):
+        return "vmem"
+    return "other"
+
+
+class AsmLoop:
+    """One wavefront running the generated loop on a raw LZMA stream."""
+
+    def __init__(self, lp0=True, gen_module=None):
+        import gen_fast_loop as G
+        self.G = gen_module or G
+        G = self.G
+        g = G.Gen(lp0)
+        g.build()
+        lines = g.main + g.cold + g.stubs
+        g.cur = lines
+        g.finish()
+        # operand -> register: scalars from s0 (4-aligned quads for the two descriptors), vectors from v0
+        fixed = getattr(G, "FIXED_OPERANDS", {})
+        self.regmap = dict(fixed)
+        s_next = 0
+        for name in G.OPS_INOUT_S + G.OPS_IN_S:
+            if name in self.regmap:
+                continue
+            if name in ("in_rsrc", "out_rsrc"):
+                s_next = (s_next + 3) & ~3
+                self.regmap[name] = "s[%d:%d]" % (s_next, s_next + 3)
+                s_next += 4
+            else:
+                self.regmap[name] = "s%d" % s_next
+                s_next += 1
+        assert s_next <= 64, "operand SGPRs collide with the generator's fixed temporaries"
+        v_next = 0
+        for name in G.OPS_INOUT_V + G.OPS_IN_V:
+            if name in self.regmap:
+                continue
+            self.regmap[name] = "v%d" % v_next
+            v_next += 1
+        assert v_next <= 64
+        self.prog = Program(lines, self.regmap)
+        self.L = _lib()
+        self.h = self.L.emu_create(self.prog.blob())
+        err = self.L.emu_error(self.h)
+        if err:
+            raise RuntimeError("emulator: " + err.decode())
+        self.n = self.L.emu_size(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.emu_destroy(self.h)
+            self.h = None
+
+    # ---- register access by operand name -------------------------------------------------------------
+    def _sidx(self, name):
+        r = self.regmap[name]
+        m = re.match(r"s\[?(\d+)", r)
+        return int(m.group(1))
+
+    def _vidx(self, name):
+        return int(re.match(r"v\[?(\d+)", self.regmap[name]).group(1))
+
+    def sset(self, name, val):
+        self.L.emu_set_s(self.h, self._sidx(name), int(val) & 0xFFFFFFFF)
+
+    def sget(self, name):
+        return self.L.emu_get_s(self.h, self._sidx(name))
+
+    def vset(self, idx, val):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(val, dtype=np.uint32), (64,)))
+        self.L.emu_set_v(self.h, idx, a.ctypes.data)
+
+    def vget(self, idx):
+        a = np.zeros(64, dtype=np.uint32)
+        self.L.emu_get_v(self.h, idx, a.ctypes.data)
+        return a
+
+    def set_rsrc(self, name, base, records):
+        i = self._sidx(name)
+        for k, w in enumerate((base & 0xFFFFFFFF, (base >> 32) & 0xFFFF, records, 0x00020000)):
+            self.L.emu_set_s(self.h, i + k, w)
+
+    # ---- the kernel around the loop (decode_fast_asm.hip.h), raw LZMA units only ------------------------------
+    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0):
+        """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode)."""
+        G = self.G
+        if out_cap is None:
+            out_cap = unpacked_size if unpacked_size is not None else len(payload) * 64 + 4096
+        in_len = len(payload)
+        IN0 = 64
+        in_span = (in_len + 63 + 128) & ~63
+        OUT0 = IN0 + in_span + 64
+        mem = np.zeros(OUT0 + out_cap + 512, dtype=np.uint8)
+        mem[IN0:IN0 + in_len] = np.frombuffer(bytes(payload), dtype=np.uint8)
+        self._mem = mem
+        self.L.emu_set_mem(self.h, mem.ctypes.data, mem.size)
+        self.L.emu_set_hwreg(self.h, hw_slot)
+        lane = np.arange(64, dtype=np.uint32)
+
+        def window(wpos):
+            w = np.zeros(64, dtype=np.uint32)
+            for l in range(64):
+                if wpos + l < in_len:
+                    w[l] = payload[wpos + l]
+            return w
+
+        # model reset (reset_model)
+        for name in G.OPS_INOUT_V:
+            if name.startswith("m_") or name in ("u0", "u1", "u2", "u3"):
+                self.vset(self._vidx(name), 0x400)
+        for i in range(16):
+            self.vset(64 + i, 0x04000400)
+        for i in range(4):
+            self.vset(80 + i, 0x400)
+        lds = np.full(8 * 64 * 4, 0x04000400, dtype=np.uint32)
+        self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
+        self.vset(self._vidx("v_lane"), lane)
+        self.vset(self._vidx("pend_val"), 0)
+        # reader: seek(0, in_len), then rc_init
+        wbase, off, lim = 0, 0, in_len
+        if in_len < 5:
+            return dict(status=ST_RC_INIT, out=b"", len=0, in_consumed=in_len, executed=0)
+        code = int.from_bytes(bytes(payload[1:5]), "big")
+        off = 5
+        self.vset(self._vidx("winb"), window(0))
+        self.vset(self._vidx("winb_next"), window(64))
+        S = self.sset
+        S("range", 0xFFFFFFFF)
+        S("code", code)
+        S("off", off)
+        S("lim", lim)
+        S("wbase", wbase)
+        S("len", 0)
+        S("state", 0)
+        for r in ("rep0", "rep1", "rep2", "rep3"):
+            S(r, 0)
+        S("prev", 0)
+        S("mb", 0xFFFFFFFF)
+        S("pend_n", 0)
+        S("pend_pos", 0)
+        S("cur_row", 0)
+        S("mlen", 0)
+        S("exitcode", 0)
+        for p in ("prof_wm", "prof_nm", "prof_wc", "prof_nc"):
+            S(p, 0)
+        known = unpacked_size is not None
+        clamped = known and unpacked_size > 0xFFFFFFFF
+        S("known", 1 if known else 0)
+        S("target", unpacked_size if (known and not clamped) else 0xFFFFFFFF)
+        out_lim = out_cap
+        S("out_lim", out_lim)
+        S("safe_len", out_lim - 273 if out_lim >= 273 else 0)
+        S("dict_size", dict_size)
+        S("lc", lc)
+        S("lc8", 8 - lc)
+        S("lpmask", (1 << lp) - 1)
+        S("pbmask", (1 << pb) - 1)
+        S("ldsbase", 0)
+        self.set_rsrc("in_rsrc", IN0, in_len)
+        self.set_rsrc("out_rsrc", OUT0, out_cap)
+        executed = 0
+        status = None
+        while True:
+            n = self.L.emu_run(self.h, 0, max_steps)
+            if n < 0:
+                raise RuntimeError("emulator: " + self.L.emu_error(self.h).decode())
+            executed += n
+            ex = self.sget("exitcode")
+            if ex != G.EXIT["LZ_SLOW"]:
+                break
+            # append_lz_slow: matches of >= 64 bytes or running into the output limit
+            ln, mlen, dist = self.sget("len"), self.sget("mlen"), self.sget("rep0") + 1
+            nb = mlen
+            clipped = False
+            if ln + mlen > out_lim:
+                nb = max(0, out_lim - ln)
+                clipped = True
+            for i in range(nb):
+                mem[OUT0 + ln + i] = mem[OUT0 + ln - dist + i]
+            S("pend_n", G.PEND_UNKNOWN)
+            S("mb", 0xFFFFFFFF)
+            if clipped:
+                if known and out_lim >= unpacked_size:
+                    S("len", ln + mlen)
+                    continue
+                S("len", ln + nb)
+                status = "OUT_FULL"
+                break
+            S("len", ln + mlen)
+        ln = self.sget("len")
+        if status is None:
+            name = {v: k for k, v in G.EXIT.items()}[ex]
+            if name == "DONE_SIZE":
+                status = ST_OK if ln == unpacked_size else "SIZE_MISMATCH"
+            elif name == "DONE_FIN":
+                status = ST_OK
+            elif name == "MARKER":
+                rem = self.sget("lim") - self.sget("off")
+                status = ST_OK if (rem == 0 and self.sget("code") == 0) else "MARKER_TRAILING"
+            elif name == "LIMIT":
+                status = "OUT_FULL"
+            else:
+                status = name
+        in_consumed = self.sget("wbase") + self.sget("off")
+        if status == ST_INPUT_EOF:
+            in_consumed = in_len
+        return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,
+                    executed=executed)
+
+    # ---- executed-instruction statistics ------------------------------------------------------------------
+    def counts(self):
+        c = np.zeros(self.n, dtype=np.uint64)
+        t = np.zeros(self.n, dtype=np.uint64)
+        self.L.emu_counts(self.h, c.ctypes.data, t.ctypes.data)
+        return c, t
+
+    def reset_counts(self):
+        self.L.emu_reset_counts(self.h)
+
+    def mix(self):
+        """executed instructions per class, and taken branches"""
+        c, t = self.counts()
+        out = {}
+        for i, text in enumerate(self.prog.text):
+            k = classify(text)
+            out[k] = out.get(k, 0) + int(c[i])
+        out["taken"] = int(t.sum())
+        out["total"] = int(c.sum())
+        return out

@@ -40,7 +40,8 @@ struct Ins {
   X(s_cmpk_eq_u32) X(s_cmpk_lg_u32) X(s_cmpk_gt_u32) X(s_cmpk_ge_u32) X(s_cmpk_lt_u32) X(s_cmpk_le_u32)                \
   X(s_bitcmp1_b32) X(s_bitcmp0_b32) X(s_bitcmp1_b64) X(s_branch) X(s_cbranch_scc0) X(s_cbranch_scc1)                   \
   X(s_cbranch_vccnz) X(s_cbranch_vccz) X(s_cbranch_execz) X(s_nop) X(s_waitcnt) X(s_getpc_b64) X(s_setpc_b64)          \
-  X(s_call_b64) X(s_set_gpr_idx_on) X(s_set_gpr_idx_off) X(s_addk_i32) X(s_sleep) X(s_abs_i32)                         \
+  X(s_call_b64) X(s_set_gpr_idx_on) X(s_set_gpr_idx_off) X(s_addk_i32) X(s_sleep) X(s_abs_i32) X(s_setprio)  \
+  X(s_getreg_b32) X(s_memtime) X(s_memrealtime)                         \
   X(v_mov_b32) X(v_readlane_b32) X(v_readfirstlane_b32) X(v_writelane_b32) X(v_lshrrev_b32) X(v_lshlrev_b32)           \
   X(v_ashrrev_i32) X(v_add_u32) X(v_sub_u32) X(v_subrev_u32) X(v_and_b32) X(v_or_b32) X(v_xor_b32)                     \
   X(v_mul_u32_u24) X(v_mad_u32_u24) X(v_mul_lo_u32) X(v_cndmask_b32) X(v_cmp_lt_u32) X(v_cmp_eq_u32) X(v_cmp_gt_u32)   \
@@ -79,8 +80,9 @@ struct Emu {
   uint8_t* mem;
   uint64_t mem_size;
   uint64_t executed;
+  uint32_t hwreg;
   std::string err;
-  Emu() : vcc(0), scc(0), m0(0), idx_mode(0), idx_on(false), lds(65536 * 3, 0), mem(nullptr), mem_size(0), executed(0) {
+  Emu() : vcc(0), scc(0), m0(0), idx_mode(0), idx_on(false), lds(65536 * 3, 0), mem(nullptr), mem_size(0), executed(0), hwreg(0) {
     memset(s, 0, sizeof(s));
     memset(v, 0, sizeof(v));
   }
@@ -100,7 +102,7 @@ inline uint32_t as_u(float f) {
 // scalar-side read of an operand (SGPR, immediate, vcc low); lane-side read adds VGPRs
 inline uint32_t rs(Emu& e, const Arg& a) {
   switch (a.kind) {
-    case K_S: return e.s[a.val];
+    case K_S: return a.val == 124 ? e.m0 : e.s[a.val];  // (124 = M0)
     case K_I: return a.val;
     case K_VCC: return uint32_t(e.vcc);
     default: e.err = "scalar read of a non-scalar operand"; return 0;
@@ -115,8 +117,10 @@ inline uint64_t rs64(Emu& e, const Arg& a) {
   }
 }
 inline void ws(Emu& e, const Arg& a, uint32_t x) {
-  if (a.kind == K_S) e.s[a.val] = x;
-  else if (a.kind == K_VCC) e.vcc = (e.vcc & 0xFFFFFFFF00000000ull) | x;
+  if (a.kind == K_S) {
+    if (a.val == 124) e.m0 = x;
+    else e.s[a.val] = x;
+  } else if (a.kind == K_VCC) e.vcc = (e.vcc & 0xFFFFFFFF00000000ull) | x;
   else e.err = "scalar write to a non-scalar operand";
 }
 inline void ws64(Emu& e, const Arg& a, uint64_t x) {
@@ -261,6 +265,10 @@ long run(Emu& e, int start, long max_steps) {
       case OP_s_cbranch_vccnz: if (e.vcc != 0) { next = int(I.a[0].val); e.taken[pc]++; } break;
       case OP_s_cbranch_vccz: if (e.vcc == 0) { next = int(I.a[0].val); e.taken[pc]++; } break;
       case OP_s_cbranch_execz: break;  // EXEC is never zero here
+      case OP_s_getreg_b32: ws(e, I.a[0], e.hwreg); break;  // (whatever field is asked for: the value the test set)
+      case OP_s_memtime:
+      case OP_s_memrealtime: ws64(e, I.a[0], e.executed + uint64_t(steps)); break;
+      case OP_s_setprio:
       case OP_s_nop:
       case OP_s_sleep:
       case OP_s_waitcnt: break;
@@ -511,6 +519,7 @@ void emu_set_s(void* h, int i, uint32_t x) { static_cast<Emu*>(h)->s[i] = x; }
 uint32_t emu_get_s(void* h, int i) { return static_cast<Emu*>(h)->s[i]; }
 void emu_set_v(void* h, int i, const uint32_t* lanes) { memcpy(static_cast<Emu*>(h)->v[i], lanes, 256); }
 void emu_get_v(void* h, int i, uint32_t* lanes) { memcpy(lanes, static_cast<Emu*>(h)->v[i], 256); }
+void emu_set_hwreg(void* h, uint32_t x) { static_cast<Emu*>(h)->hwreg = x; }
 void emu_set_vcc(void* h, uint64_t x) { static_cast<Emu*>(h)->vcc = x; }
 void emu_lds_write(void* h, uint32_t off, const uint8_t* src, uint32_t n) { memcpy(&static_cast<Emu*>(h)->lds[off], src, n); }
 void emu_lds_read(void* h, uint32_t off, uint8_t* dst, uint32_t n) { memcpy(dst, &static_cast<Emu*>(h)->lds[off], n); }

@@ -47,10 +47,14 @@ PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb ar
 K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
 LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of the match-source load (experiments)
 STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
-WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
+WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"
+WAITPROF2 = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "2"  # tuning: isolated round trips of a literal's byte store / a match's load  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
 INTERLEAVE = os.environ.get("MILZMA_GEN_INTERLEAVE", "0") == "1"  # alternate scalar and vector instructions inside a tree decision (measured: -1 %)
 DEFER = os.environ.get("MILZMA_GEN_DEFER", "1") == "1"  # update a tree's probabilities once per tree walk, from the final symbol
-JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"  # enter the chain of direct bits with a computed jump instead of looping
+JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"
+# pos_slot -> (distance base, jump target) through two per-lane constant tables instead of ~15 scalar instructions and
+# three branches per match
+TABLES = os.environ.get("MILZMA_GEN_TABLES", "1") == "1"  # enter the chain of direct bits with a computed jump instead of looping
 PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
@@ -64,20 +68,31 @@ PAD_B = int(os.environ.get("MILZMA_GEN_PAD_B", "0"))
 # with the youngest.  PRIO = k > 0: every window refill sets s_setprio ((len >> k) + wave slot) & 3, so that the four waves
 # of a SIMD take turns at every priority and finish together.  PRIO = -1: static priority = wave slot (diagnostic).
 PRIO = int(os.environ.get("MILZMA_GEN_PRIO", "12"))
-NORM_S = os.environ.get("MILZMA_GEN_NORM_S", "0") == "1"  # the "range < 2^24" test on the scalar ALU instead of the vector ALU
+# Decision "form B": range and code live in the adjacent pair s[66:67]; the vector ALU also delivers range - bound, both are
+# read into scalar pairs and ONE s_cselect_b64 picks (bound, code) or (range - bound, code - bound): 3 scalar + 5 vector
+# instructions and no wait state, against 5 + 3 + s_nop for form A.  Measured marginal cost (dead-instruction probes, r02):
+# a scalar instruction per byte costs 3x what a vector instruction does.  FORMB: comma list of where it is used
+# (tree = deferred-update tree walks, single = is_match / is_rep / choice ..., lit = literal levels 6-7 and matched literals).
+FORMB = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_FORMB", "tree"))))
+# the "range < 2^24" test on the scalar ALU (s_cmp_lt_u32 + s_cbranch_scc1) instead of the vector ALU (v_cmp + s_cbranch_vccnz):
+# list of site kinds (tree, single, lit, direct), or 1 = everywhere
+NORM_S = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_NORM_S", "1"))))
+if "1" in NORM_S:
+    NORM_S = {"tree", "single", "lit", "direct"}
 
 
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pad="s69", prioph="s68", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
+         c2017="s90", c2048="s91", pad="s69", prioph="s68", jb_lo="s64", jb_hi="s65", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
+JBASE = "s[64:65]"  # address of Lbase (set once per entry): jump targets are table offsets from it
 RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
          VLANE192="v101", vb="v102", VSH6="v103", VSH6M1="v104", VSH5="v105", VSH5M1="v106", VSH4="v107",
-         VSH4M1="v108", VLEVEL="v109", va="v110")
+         VSH4M1="v108", VLEVEL="v109", va="v110", vr="v112")
 if PAD_V:
     V["vpad"] = "v111"
 MROW = "v[84:87]"
@@ -91,13 +106,16 @@ EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, 
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
-               "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc"]
+               "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc", "tbl_ready"]
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
-               "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val"]
+               "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val", "tbl_a", "tbl_b"]
 OPS_IN_S = ["out_lim", "safe_len", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
             "out_rsrc", "ldsbase"]
 OPS_IN_V = ["v_lane"]
+FIXED_OPERANDS = {"range": "s66", "code": "s67"}   # an aligned pair, for s_cselect_b64
+RC = "s[66:67]"
+RC1 = "s[74:75]"                                   # (sr1, sc1)
 
 
 def R(name):
@@ -105,6 +123,8 @@ def R(name):
         return S[name]
     if name in V:
         return V[name]
+    if name in FIXED_OPERANDS:
+        return FIXED_OPERANDS[name]
     return "%%[%s]" % name
 
 
@@ -148,11 +168,11 @@ class Gen:
         return Gen._Into(self, self.cold)
 
     # ---- range coder ------------------------------------------------------------------------------
-    def norm(self, to=None):
+    def norm(self, to=None, kind="single"):
         """RangeDecoder::normalize (rangecoder.rs:59-69) as a check + out-of-line stub.
         `to`: label to continue at (default: fall through)."""
         k = self.new("N")
-        if NORM_S:
+        if kind in NORM_S:
             self.e("s_cmp_lt_u32 {range}, 0x1000000")
             self.e("s_cbranch_scc1 " + self.L(k))
         else:
@@ -186,11 +206,25 @@ class Gen:
         for _ in range(PAD_B):
             self.e("s_cbranch_execz " + self.L("finish"))
 
-    def core(self, T, ln, half=None, cmp_lane=None):
+    def core(self, T, ln, half=None, cmp_lane=None, formb=False):
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
         0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
         self.pad()
+        if ("lit" if half is not None else "single") in FORMB or formb:
+            self.e("v_lshrrev_b32 {vt}, 11, {range}")
+            if half == 0:
+                self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
+            elif half == 1:
+                self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
+            self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
+            self.e("v_sub_u32 {vr}, {range}, {vb}")
+            self.e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)      # (bound, code)
+            self.e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)        # range - bound
+            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
+            self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
+            self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
+            return
         if BOUND_ON_VALU:
             # every lane computes the bound of its own probability; the one that is needed is read out
             self.e("v_lshrrev_b32 {vt}, 11, {range}")
@@ -295,6 +329,17 @@ class Gen:
         4 vector instructions and a wait state"""
         e = self.e
         self.pad()
+        if "tree" in FORMB:
+            e("v_lshrrev_b32 {vt}, 11, {range}")
+            e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
+            e("v_sub_u32 {vr}, {range}, {vb}")
+            e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)           # (bound, code)
+            e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)             # range - bound
+            e("s_sub_u32 {sc1}, {code}, {range}")                    # SCC = code < bound  <=>  bit == 0
+            e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
+            e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
+            self.norm(kind="tree")
+            return
         e("v_lshrrev_b32 {vt}, 11, {range}")
         e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
         e("s_nop 0")  # gfx940: one wait state between a VALU write and the v_readlane of it (measured: without it every stream decodes wrongly)
@@ -304,7 +349,7 @@ class Gen:
         e("s_cselect_b32 {range}, {sb}, {sr1}")
         e("s_cselect_b32 {code}, {code}, {sc1}")
         e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
-        self.norm()
+        self.norm(kind="tree")
 
     def tree_walk(self, T, nbits, first_lane=None):
         """nbits decisions down a heap-numbered tree in T (lane = running symbol).  first_lane: constant
@@ -357,7 +402,7 @@ class Gen:
         self.e("s_sub_u32 {sc1}, {code}, {range}")
         self.e("s_cselect_b32 {code}, {code}, {sc1}")
         self.e("s_addc_u32 {a}, {a}, {a}", a=acc)
-        self.norm()
+        self.norm(kind="direct")
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False, prof=None, extract=True):
@@ -387,6 +432,52 @@ class Gen:
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
 
+    def tables_prologue(self):
+        """tbl_a[lane] / tbl_b[lane] for lane = the pos_slot walk's final symbol & 63 (the inverted path: slot = lane ^ 63):
+        tbl_b = byte offset from Lbase of the code that continues this slot's distance (slots >= 14: the entry into the
+        chain of 26 direct-bit blocks that leaves exactly (slot >> 1) - 5 of them to run; 4..13: dist_rev; < 4:
+        dist_small); tbl_a = ((3 + (slot & 1)) << ndb) - 1 for slots >= 14 (what the inverted direct / align bits are
+        subtracted from, lzma.rs:576-590), (2 | (slot & 1)) << ndb for 4..13, the slot itself below 4.
+        Computed once per unit (tbl_ready), the base address once per entry."""
+        e, L = self.e, self.L
+        e("s_getpc_b64 " + JBASE)
+        self.lab("base")
+        e("s_cmp_lg_u32 {tbl_ready}, 0")
+        e("s_cbranch_scc1 " + L("tbl_done"))
+        bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
+        e("v_xor_b32 {VT0}, 63, {v_lane}")                 # slot
+        e("v_lshrrev_b32 {VT1}, 1, {VT0}")
+        e("v_and_b32 {VT2}, 1, {VT0}")
+        e("v_sub_u32 {vt}, 31, {VT1}")                     # 26 - count
+        e("v_mul_u32_u24 {vt}, " + bs + ", {vt}")
+        e("v_add_u32 {tbl_b}, " + L("direct_chain") + "-" + L("base") + ", {vt}")
+        e("v_mov_b32 {vx}, " + L("dist_rev") + "-" + L("base"))
+        e("v_cmp_gt_u32 vcc, 14, {VT0}")
+        e("s_nop 0")
+        e("s_nop 0")
+        e("v_cndmask_b32 {tbl_b}, {tbl_b}, {vx}, vcc")
+        e("v_mov_b32 {vx}, " + L("dist_small") + "-" + L("base"))
+        e("v_cmp_gt_u32 vcc, 4, {VT0}")
+        e("s_nop 0")
+        e("s_nop 0")
+        e("v_cndmask_b32 {tbl_b}, {tbl_b}, {vx}, vcc")
+        e("v_add_u32 {vb}, -1, {VT1}")                     # ndb
+        e("v_add_u32 {vt}, 3, {VT2}")
+        e("v_lshlrev_b32 {vt}, {vb}, {vt}")
+        e("v_add_u32 {vt}, -1, {vt}")
+        e("v_add_u32 {vx}, 2, {VT2}")
+        e("v_lshlrev_b32 {vx}, {vb}, {vx}")
+        e("v_cmp_gt_u32 vcc, 14, {VT0}")
+        e("s_nop 0")
+        e("s_nop 0")
+        e("v_cndmask_b32 {tbl_a}, {vt}, {vx}, vcc")
+        e("v_cmp_gt_u32 vcc, 4, {VT0}")
+        e("s_nop 0")
+        e("s_nop 0")
+        e("v_cndmask_b32 {tbl_a}, {tbl_a}, {VT0}, vcc")
+        e("s_mov_b32 {tbl_ready}, 1")
+        self.lab("tbl_done")
+
     def set_prio(self, reg, tmp):
         """s_setprio takes an immediate: a short chain picks the instruction for reg & 3 (clobbers SCC and tmp)"""
         done = self.new("P")
@@ -397,6 +488,20 @@ class Gen:
             self.e("s_cbranch_scc1 " + self.L(done))
         self.e("s_setprio 3")
         self.lab(done)
+
+    def prof_begin(self):
+        self.e("s_waitcnt vmcnt(0)")                       # nothing older in flight: the next operation is timed alone
+        self.e("s_memtime s[94:95]")
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e("s_mov_b32 s96, s94")
+
+    def prof_end(self, which):
+        self.e("s_waitcnt vmcnt(0)")
+        self.e("s_memtime s[94:95]")
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e("s_sub_u32 s96, s94, s96")
+        self.e("s_add_u32 {w}, {w}, s96", w=R("prof_w" + which))
+        self.e("s_add_u32 {n}, {n}, 1", n=R("prof_n" + which))
 
     def exit_with(self, code):
         self.e("s_mov_b32 {exitcode}, %d" % EXIT[code])
@@ -523,7 +628,11 @@ class Gen:
         e("s_cbranch_scc1 " + L("Xlimit"))
         e("v_mov_b32 {VT0}, {prev}")
         e("v_or_b32 {VT1}, {len}, {VOOB}")
+        if WAITPROF2:
+            self.prof_begin()
         e("buffer_store_byte {VT0}, {VT1}, {out_rsrc}, 0 offen" + STORE_MOD)
+        if WAITPROF2:
+            self.prof_end("m")
         e("s_add_u32 {len}, {len}, 1")
         e("s_branch " + L("topL"))
 
@@ -541,181 +650,9 @@ class Gen:
         self.lab("lit_r" + tag)
         self.row_swap_stub("Orow_swap" + tag, "lit_r" + tag)
 
-    # ---- the loop ------------------------------------------------------------------------------------------
-    def build(self):
+    def distance_scalar(self):
+        """decode_distance with the slot arithmetic on the scalar ALU (the round-1 form)"""
         e, lab, L = self.e, self.lab, self.L
-        # prologue: per-lane constants
-        e("v_cmp_eq_u32 vcc, 0, {v_lane}")
-        e("v_lshl_add_u32 {VL16}, {v_lane}, 4, {ldsbase}")
-        e("v_mov_b32 {VKTOP}, 0x1000000")
-        e("v_add_u32 {VLANE64}, 64, {v_lane}")
-        e("v_add_u32 {VLANE128}, 0x80, {v_lane}")
-        e("v_add_u32 {VLANE192}, 0xc0, {v_lane}")
-        e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
-        e("s_movk_i32 {c2017}, 2017")
-        e("s_movk_i32 {c2048}, 0x800")
-        e("s_cmpk_gt_u32 {lim}, 63")
-        e("s_cselect_b32 {gtop}, {target}, 0")
-        e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
-        if PRIO:
-            e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD
-            if PRIO < 0:
-                self.set_prio(R("prioph"), R("n0"))
-        if DEFER:                                            # per-lane heap level and the shifts tree_update uses
-            e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
-            e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
-            e("v_sub_u32 {VSH6}, 6, {VLEVEL}")
-            e("v_sub_u32 {VSH6M1}, 5, {VLEVEL}")
-            e("v_sub_u32 {VSH5}, 5, {VLEVEL}")
-            e("v_sub_u32 {VSH5M1}, 4, {VLEVEL}")
-            e("v_sub_u32 {VSH4}, 4, {VLEVEL}")
-            e("v_sub_u32 {VSH4M1}, 3, {VLEVEL}")
-        # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
-        # prev at hand: a literal here is a plain one) and "M" after a match (state >= 7: a literal here is
-        # a matched one and first completes the pending match).
-        e("s_cmpk_ge_u32 {state}, 7")
-        e("s_cbranch_scc1 " + L("topM"))
-        e("s_cmp_lg_u32 {pend_n}, 0")                    # entered from C++ with prev unknown
-        e("s_cbranch_scc1 " + L("Oentry_fix"))
-
-        # ================= after a literal =================
-        self.symbol_top("L")
-        # ---- plain literal (lzma.rs:526-561)
-        self.literal_row("L")
-        e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
-        e("s_max_i32 {state}, {state}, 0")
-        if DEFER:                   # nodes 1..63 -> u0
-            self.tree_walk(R("u0"), 6, first_lane="1")
-            self.tree_update(R("u0"), 6)
-            with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
-                for i in range(1, 6):   # only the levels from pl0 on were walked in u0
-                    lab("plain%d" % i)
-                    self.bit_nu(R("u0"), R("sym"))
-                self.tree_update(R("u0"), 6, min_level=R("pl0"))
-                e("s_branch " + L("plain6"))
-        else:
-            for i in range(6):
-                if i:
-                    lab("plain%d" % i)
-                self.bit(R("u0"), "1" if i == 0 else R("sym"), first=i == 0)
-        lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
-        self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
-        lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
-        e("s_bitcmp1_b32 {sym}, 6")
-        e("s_cbranch_scc1 " + L("plain7_hi"))
-        self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
-        lab("lit_done")
-        self.literal_epilogue()
-        with self.in_cold():
-            lab("plain7_hi")
-            self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
-            self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
-
-        # ================= after a match =================
-        self.symbol_top("M")
-        # ---- matched literal: probs[((1 + match_bit) << 8) + sym] (lzma.rs:541-555).  The row's two
-        #      matched sub-tables are in LDS, dword k of a lane = nodes 64k..64k+63, low half for
-        #      match_bit 0 and high half for match_bit 1.
-        e("s_add_u32 {t6}, {pend_n}, -1")                # complete the pending match, unless (rare) there is none
-        e("s_cmpk_ge_u32 {t6}, 0x%x" % (PEND_UNKNOWN - 1))  # (pend_n == 0, entering from C++) or prev / mb are unknown
-        e("s_cbranch_scc1 " + L("OpendM_special"))
-        self.finish_pending(have_t6=True, prof="m")
-        lab("lit_pM")
-        self.literal_row("M")
-        e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
-        e("s_cselect_b32 {t1}, 3, 6")
-        e("s_sub_u32 {state}, {state}, {t1}")
-        e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
-        e("s_cmp_gt_u32 {t0}, {dict_size}")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
-        e("s_cmp_gt_u32 {t0}, {len}")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_out"))
-        e("s_cmp_eq_u32 {mb}, -1")
-        e("s_cbranch_scc1 " + L("Omb_fetch"))
-        lab("lm_a")
-        e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
-        e("ds_read_b128 " + MROW + ", {VA}")
-        e("s_waitcnt lgkmcnt(0)")
-        # levels 0..6 (a mismatch continues in the plain chain): one code chain per value of the match
-        # bit, so that a branch is only taken when the match bit differs from the previous level's
-        e("s_bitcmp1_b32 {mb}, 7")
-        e("s_cbranch_scc1 " + L("lm0_1"))
-        for m in (0, 1):
-            ctx = None if m == 0 else self.in_cold()
-            if ctx:
-                ctx.__enter__()
-            for i in range(7):
-                lab("lm%d_%d" % (i, m))
-                first = i == 0
-                T = V["M0"] if i < 6 else V["M1"]
-                lnreg = "1" if first else R("sym")
-                cl = V["VLANE64"] if i == 6 else None
-                acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
-                mis = self.new("MIS")
-                self.core(T, lnreg, half=m, cmp_lane=cl)
-                # still matched if the decoded bit equals the match bit: SCC = (bit == 0)
-                e(("s_cbranch_scc0 " if m == 0 else "s_cbranch_scc1 ") + L(mis))
-                e(acc)
-                self.post_known(T, m == 0, half=m)
-                self.norm()
-                with Gen._Into(self, self.stubs):         # (not the cold list: the m == 1 chain lives there)
-                    lab(mis)
-                    e(acc)
-                    self.post_known(T, m != 0, half=m)
-                    e("ds_write_b128 {VA}, " + MROW)
-                    if DEFER and i + 1 < 6:
-                        e("s_mov_b32 {pl0}, %d" % (i + 1))
-                    self.norm(to="plain%d" % (i + 1))
-                if i < 6:
-                    e("s_bitcmp1_b32 {mb}, %d" % (7 - (i + 1)))   # the next match bit picks the sub-table
-                    e(("s_cbranch_scc1 " if m == 0 else "s_cbranch_scc0 ") + L("lm%d_%d" % (i + 1, 1 - m)))
-                elif m == 1:
-                    e("s_branch " + L("lm7"))
-            if ctx:
-                ctx.__exit__()
-        lab("lm7")                   # last level: nodes 128..191 in M2, 192..255 in M3; nothing follows a mismatch
-        e("s_bitcmp1_b32 {sym}, 6")
-        e("s_cbranch_scc1 " + L("lm7_hi"))
-        e("s_bitcmp1_b32 {mb}, 0")
-        e("s_cbranch_scc1 " + L("lm7_lo_m1"))
-        self.core(V["M2"], R("sym"), half=0, cmp_lane=V["VLANE128"])
-        self.pre_sym()
-        e("s_addc_u32 {sym}, {sym}, {sym}")
-        self.post_sym(V["M2"], half=0)
-        lab("lm_full")
-        e("ds_write_b128 {VA}, " + MROW)
-        self.norm(to="lit_done")
-        with self.in_cold():
-            for name, T, half, pre, cl in [("lm7_lo_m1", "M2", 1, None, "VLANE128"), ("lm7_hi", "M3", 0, "lm7_hi_m1", "VLANE192"),
-                                           ("lm7_hi_m1", "M3", 1, None, "VLANE192")]:
-                lab(name)
-                if pre:
-                    e("s_bitcmp1_b32 {mb}, 0")
-                    e("s_cbranch_scc1 " + L(pre))
-                self.core(V[T], R("sym"), half=half, cmp_lane=V[cl])
-                self.pre_sym()
-                e("s_addc_u32 {sym}, {sym}, {sym}")
-                self.post_sym(V[T], half=half)
-                e("s_branch " + L("lm_full"))
-            lab("OpendM_special")
-            e("s_cmp_eq_u32 {pend_n}, 0")
-            e("s_cbranch_scc1 " + L("lit_pM"))
-            self.prev_fetch("lit_pM")                         # lzb.last_or(0) when the previous byte is not at hand
-            lab("Oentry_fix")
-            self.prev_fetch("topL")
-
-        # ================= match (lzma.rs:480-523) =================
-        lab("match")
-        self.taken(R("m_ismatch"))
-        self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
-        e("s_mov_b32 {rep3}, {rep2}")
-        e("s_mov_b32 {rep2}, {rep1}")
-        e("s_mov_b32 {rep1}, {rep0}")
-        self.len_decode(0, "len0_done")
-        e("s_cmpk_lt_u32 {state}, 7")
-        e("s_cselect_b32 {state}, 7, 10")
-        # ---- decode_distance (lzma.rs:563-592)
         e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2
         e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
         e("v_mov_b32 {VPS}, " + PS0M2)
@@ -830,6 +767,253 @@ class Gen:
             e("s_add_u32 {rep0}, {t2}, {t4}")
             e("s_branch " + L("copy"))
 
+    def distance_tables(self):
+        """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
+        for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
+        e, lab, L = self.e, self.lab, self.L
+        e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2  (gfx9 has no v_movrel*: s_set_gpr_idx)
+        e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
+        e("v_mov_b32 {VPS}, " + PS0M2)
+        e("s_set_gpr_idx_off")
+        self.tree_walk(V["VPS"], 6, first_lane="1")
+        self.tree_update(V["VPS"], 6)
+        e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
+        e("v_mov_b32 " + PS0M2 + ", {VPS}")
+        e("s_set_gpr_idx_off")
+        e("v_readlane_b32 {t2}, {tbl_a}, {sym}")
+        e("v_readlane_b32 {t5}, {tbl_b}, {sym}")
+        e("s_mov_b32 {t4}, 0")
+        e("s_add_u32 " + JPAIR_LO + ", {jb_lo}, {t5}")
+        e("s_addc_u32 " + JPAIR_HI + ", {jb_hi}, 0")
+        e("s_setpc_b64 " + JPAIR)
+        lab("direct_chain")
+        for _ in range(26):
+            self.direct_bit(R("t4"))
+        lab("direct_done")
+        self.tree_walk(R("m_align"), 4, first_lane="1")
+        self.tree_update(R("m_align"), 4)
+        e("s_lshl_b32 {t4}, {t4}, 4")
+        e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
+        e("s_brev_b32 {t3}, {t3}")                           # a'
+        e("s_add_u32 {t4}, {t4}, {t3}")
+        e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
+        e("s_branch " + L("copy"))
+        with self.in_cold():
+            lab("dist_small")
+            e("s_mov_b32 {rep0}, {t2}")
+            e("s_branch " + L("copy"))
+            # slots 4..11: pos_decoders[result - slot + node] in m_posdec_a, ndb = 1..4 bits;
+            # slots 12, 13: m_posdec_b lanes (slot - 12) * 32 + node, 5 bits
+            lab("dist_rev")
+            e("s_xor_b32 {t0}, {sym}, 0x7f")                    # pos_slot
+            e("s_lshr_b32 {t1}, {t0}, 1")
+            e("s_add_u32 {t1}, {t1}, -1")                       # num_direct_bits;  t2 = (2 | (slot & 1)) << ndb (table)
+            e("s_cmp_lt_u32 {t0}, 12")
+            e("s_cbranch_scc0 " + L("dist_rev_b"))
+            e("s_sub_u32 {t6}, {t2}, {t0}")
+            e("s_mov_b32 {sym}, 1")
+            for i in range(1, 5):
+                e("s_add_u32 {ln}, {t6}, {sym}")
+                self.bit(R("m_posdec_a"), R("ln"))
+                if i < 4:
+                    e("s_cmp_eq_u32 {t1}, %d" % i)
+                    e("s_cbranch_scc1 " + L("dist_rev_fin"))
+            lab("dist_rev_fin")
+            e("s_not_b32 {t4}, {sym}")
+            e("s_sub_u32 {t3}, 32, {t1}")
+            e("s_lshl_b32 {t4}, {t4}, {t3}")
+            e("s_brev_b32 {t4}, {t4}")
+            e("s_add_u32 {rep0}, {t2}, {t4}")
+            e("s_branch " + L("copy"))
+            lab("dist_rev_b")
+            e("s_add_u32 {t6}, {t0}, -12")
+            e("s_lshl_b32 {t6}, {t6}, 5")
+            self.reverse_tree_based(R("m_posdec_b"), R("t6"), 5, R("t4"))
+            e("s_add_u32 {rep0}, {t2}, {t4}")
+            e("s_branch " + L("copy"))
+
+    # ---- the loop ------------------------------------------------------------------------------------------
+    def build(self):
+        e, lab, L = self.e, self.lab, self.L
+        # prologue: per-lane constants
+        e("v_cmp_eq_u32 vcc, 0, {v_lane}")
+        e("v_lshl_add_u32 {VL16}, {v_lane}, 4, {ldsbase}")
+        e("v_mov_b32 {VKTOP}, 0x1000000")
+        e("v_add_u32 {VLANE64}, 64, {v_lane}")
+        e("v_add_u32 {VLANE128}, 0x80, {v_lane}")
+        e("v_add_u32 {VLANE192}, 0xc0, {v_lane}")
+        e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
+        e("s_movk_i32 {c2017}, 2017")
+        e("s_movk_i32 {c2048}, 0x800")
+        e("s_cmpk_gt_u32 {lim}, 63")
+        e("s_cselect_b32 {gtop}, {target}, 0")
+        e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
+        if TABLES:
+            self.tables_prologue()
+        if PRIO:
+            e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD
+            if PRIO < 0:
+                self.set_prio(R("prioph"), R("n0"))
+        if DEFER:                                            # per-lane heap level and the shifts tree_update uses
+            e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
+            e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
+            e("v_sub_u32 {VSH6}, 6, {VLEVEL}")
+            e("v_sub_u32 {VSH6M1}, 5, {VLEVEL}")
+            e("v_sub_u32 {VSH5}, 5, {VLEVEL}")
+            e("v_sub_u32 {VSH5M1}, 4, {VLEVEL}")
+            e("v_sub_u32 {VSH4}, 4, {VLEVEL}")
+            e("v_sub_u32 {VSH4M1}, 3, {VLEVEL}")
+        # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
+        # prev at hand: a literal here is a plain one) and "M" after a match (state >= 7: a literal here is
+        # a matched one and first completes the pending match).
+        e("s_cmpk_ge_u32 {state}, 7")
+        e("s_cbranch_scc1 " + L("topM"))
+        e("s_cmp_lg_u32 {pend_n}, 0")                    # entered from C++ with prev unknown
+        e("s_cbranch_scc1 " + L("Oentry_fix"))
+
+        # ================= after a literal =================
+        self.symbol_top("L")
+        # ---- plain literal (lzma.rs:526-561)
+        self.literal_row("L")
+        e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
+        e("s_max_i32 {state}, {state}, 0")
+        if DEFER:                   # nodes 1..63 -> u0
+            self.tree_walk(R("u0"), 6, first_lane="1")
+            self.tree_update(R("u0"), 6)
+            with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
+                for i in range(1, 6):   # only the levels from pl0 on were walked in u0
+                    lab("plain%d" % i)
+                    self.bit_nu(R("u0"), R("sym"))
+                self.tree_update(R("u0"), 6, min_level=R("pl0"))
+                e("s_branch " + L("plain6"))
+        else:
+            for i in range(6):
+                if i:
+                    lab("plain%d" % i)
+                self.bit(R("u0"), "1" if i == 0 else R("sym"), first=i == 0)
+        lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
+        self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
+        lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
+        e("s_bitcmp1_b32 {sym}, 6")
+        e("s_cbranch_scc1 " + L("plain7_hi"))
+        self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
+        lab("lit_done")
+        self.literal_epilogue()
+        with self.in_cold():
+            lab("plain7_hi")
+            self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
+            self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
+
+        # ================= after a match =================
+        self.symbol_top("M")
+        # ---- matched literal: probs[((1 + match_bit) << 8) + sym] (lzma.rs:541-555).  The row's two
+        #      matched sub-tables are in LDS, dword k of a lane = nodes 64k..64k+63, low half for
+        #      match_bit 0 and high half for match_bit 1.
+        e("s_add_u32 {t6}, {pend_n}, -1")                # complete the pending match, unless (rare) there is none
+        e("s_cmpk_ge_u32 {t6}, 0x%x" % (PEND_UNKNOWN - 1))  # (pend_n == 0, entering from C++) or prev / mb are unknown
+        e("s_cbranch_scc1 " + L("OpendM_special"))
+        self.finish_pending(have_t6=True, prof="m")
+        lab("lit_pM")
+        self.literal_row("M")
+        e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
+        e("s_cselect_b32 {t1}, 3, 6")
+        e("s_sub_u32 {state}, {state}, {t1}")
+        e("s_add_u32 {t0}, {rep0}, 1")
+        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+        e("s_cmp_gt_u32 {t0}, {dict_size}")
+        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+        e("s_cmp_gt_u32 {t0}, {len}")
+        e("s_cbranch_scc1 " + L("Xmatch_dist_out"))
+        e("s_cmp_eq_u32 {mb}, -1")
+        e("s_cbranch_scc1 " + L("Omb_fetch"))
+        lab("lm_a")
+        e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
+        e("ds_read_b128 " + MROW + ", {VA}")
+        e("s_waitcnt lgkmcnt(0)")
+        # levels 0..6 (a mismatch continues in the plain chain): one code chain per value of the match
+        # bit, so that a branch is only taken when the match bit differs from the previous level's
+        e("s_bitcmp1_b32 {mb}, 7")
+        e("s_cbranch_scc1 " + L("lm0_1"))
+        for m in (0, 1):
+            ctx = None if m == 0 else self.in_cold()
+            if ctx:
+                ctx.__enter__()
+            for i in range(7):
+                lab("lm%d_%d" % (i, m))
+                first = i == 0
+                T = V["M0"] if i < 6 else V["M1"]
+                lnreg = "1" if first else R("sym")
+                cl = V["VLANE64"] if i == 6 else None
+                acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
+                mis = self.new("MIS")
+                self.core(T, lnreg, half=m, cmp_lane=cl)
+                # still matched if the decoded bit equals the match bit: SCC = (bit == 0)
+                e(("s_cbranch_scc0 " if m == 0 else "s_cbranch_scc1 ") + L(mis))
+                e(acc)
+                self.post_known(T, m == 0, half=m)
+                self.norm(kind="lit")
+                with Gen._Into(self, self.stubs):         # (not the cold list: the m == 1 chain lives there)
+                    lab(mis)
+                    e(acc)
+                    self.post_known(T, m != 0, half=m)
+                    e("ds_write_b128 {VA}, " + MROW)
+                    if DEFER and i + 1 < 6:
+                        e("s_mov_b32 {pl0}, %d" % (i + 1))
+                    self.norm(to="plain%d" % (i + 1), kind="lit")
+                if i < 6:
+                    e("s_bitcmp1_b32 {mb}, %d" % (7 - (i + 1)))   # the next match bit picks the sub-table
+                    e(("s_cbranch_scc1 " if m == 0 else "s_cbranch_scc0 ") + L("lm%d_%d" % (i + 1, 1 - m)))
+                elif m == 1:
+                    e("s_branch " + L("lm7"))
+            if ctx:
+                ctx.__exit__()
+        lab("lm7")                   # last level: nodes 128..191 in M2, 192..255 in M3; nothing follows a mismatch
+        e("s_bitcmp1_b32 {sym}, 6")
+        e("s_cbranch_scc1 " + L("lm7_hi"))
+        e("s_bitcmp1_b32 {mb}, 0")
+        e("s_cbranch_scc1 " + L("lm7_lo_m1"))
+        self.core(V["M2"], R("sym"), half=0, cmp_lane=V["VLANE128"])
+        self.pre_sym()
+        e("s_addc_u32 {sym}, {sym}, {sym}")
+        self.post_sym(V["M2"], half=0)
+        lab("lm_full")
+        e("ds_write_b128 {VA}, " + MROW)
+        self.norm(to="lit_done", kind="lit")
+        with self.in_cold():
+            for name, T, half, pre, cl in [("lm7_lo_m1", "M2", 1, None, "VLANE128"), ("lm7_hi", "M3", 0, "lm7_hi_m1", "VLANE192"),
+                                           ("lm7_hi_m1", "M3", 1, None, "VLANE192")]:
+                lab(name)
+                if pre:
+                    e("s_bitcmp1_b32 {mb}, 0")
+                    e("s_cbranch_scc1 " + L(pre))
+                self.core(V[T], R("sym"), half=half, cmp_lane=V[cl])
+                self.pre_sym()
+                e("s_addc_u32 {sym}, {sym}, {sym}")
+                self.post_sym(V[T], half=half)
+                e("s_branch " + L("lm_full"))
+            lab("OpendM_special")
+            e("s_cmp_eq_u32 {pend_n}, 0")
+            e("s_cbranch_scc1 " + L("lit_pM"))
+            self.prev_fetch("lit_pM")                         # lzb.last_or(0) when the previous byte is not at hand
+            lab("Oentry_fix")
+            self.prev_fetch("topL")
+
+        # ================= match (lzma.rs:480-523) =================
+        lab("match")
+        self.taken(R("m_ismatch"))
+        self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
+        e("s_mov_b32 {rep3}, {rep2}")
+        e("s_mov_b32 {rep2}, {rep1}")
+        e("s_mov_b32 {rep1}, {rep0}")
+        self.len_decode(0, "len0_done")
+        e("s_cmpk_lt_u32 {state}, 7")
+        e("s_cselect_b32 {state}, 7, 10")
+        # ---- decode_distance (lzma.rs:563-592)
+        if TABLES:
+            self.distance_tables()
+        else:
+            self.distance_scalar()
+
         # ---- rep matches (lzma.rs:483-509)
         lab("rep_match")
         self.taken(R("m_rep"))
@@ -881,8 +1065,8 @@ class Gen:
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
         lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
         e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cmp_gt_u32 {t0}, {gdist}")                       # gdist <= min(len, dict_size): beyond it, look closer
-        e("s_cbranch_scc1 " + L("Ocopy_dist"))
+        e("s_cmp_ge_u32 {rep0}, {gdist}")                     # gdist <= min(len, dict_size): beyond it (and for the
+        e("s_cbranch_scc1 " + L("Ocopy_dist"))                # end marker, rep0 = 0xFFFFFFFF), look closer
         lab("cp_dist_ok")
         e("s_cmpk_ge_u32 {mlen}, 64")
         e("s_cbranch_scc1 " + L("Xlz_slow"))
@@ -902,7 +1086,11 @@ class Gen:
         e("s_mov_b32 {pend_n}, {mlen}")
         e("s_add_u32 {len}, {len}, {mlen}")
         e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        if WAITPROF2:
+            self.prof_begin()
         e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
+        if WAITPROF2:
+            self.prof_end("c")
         e("s_branch " + L("topM"))
 
         # ================= out-of-line helpers =================
@@ -920,6 +1108,9 @@ class Gen:
             e("s_branch " + L("cp_b"))
 
             lab("Ocopy_dist")                                 # append_lz's two distance errors, in the reference's order
+            if TABLES:                                        # (only a new distance can be the marker, lzma.rs:372-382: a
+                e("s_cmp_eq_u32 {rep0}, -1")                  #  rep never is, decoding stops at the first one)
+                e("s_cbranch_scc1 " + L("Xmarker"))
             e("s_cmp_gt_u32 {t0}, {dict_size}")
             e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
             e("s_cmp_gt_u32 {t0}, {len}")
@@ -1011,7 +1202,7 @@ def main():
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
     fixed = ['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(16)] + ['"+{v%d}"(d.posslot[%d])' % (80 + i, i) for i in range(4)]
-    outs = ['[%s] "+s"(d.%s)' % (n, n) for n in OPS_INOUT_S] + ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V] + fixed
+    outs = [('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] + ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V] + fixed
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
     out.append("#define MILZMA_FAST_LOOP_OUTPUTS \\")
     out.append("  " + ", \\\n  ".join(outs))
