@@ -71,3 +71,16 @@ def test_emulated_loop_truncated_and_oversized_declared(loops):
     assert r["out"][:len(ref.out)] == ref.out          # what the reference flushed is a prefix of what was decoded
     r = loops[True].decode_raw(comp[13:], lc, lp, pb, ds, us - 5, out_cap=len(plain))
     assert r["status"] in ("OK", "SIZE_MISMATCH") and r["out"][:us - 5] == plain[:us - 5]
+
+
+@pytest.mark.parametrize("kind", ["text", "random"])
+def test_emulated_loop_output_limit(loops, kind):
+    """the output slice ends before the stream does: the loop stops exactly at the limit, whether a literal
+    (append_literal, lzbuffer.rs:206-217) or a match (append_lz) hits it, and everything before it is right"""
+    plain = W.make_plain(kind, 6000, seed=11)
+    comp = W.compress_alone(plain, dict_size=65536, known_size=True)
+    lc, lp, pb, ds, us = _hdr(comp)
+    for cap in (1, 2, 100, 273, 274, 1000, 5726, 5727, 5999):
+        r = loops[True].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=cap)
+        assert r["status"] == "OUT_FULL", (cap, r["status"])
+        assert r["len"] == cap and r["out"] == plain[:cap]

@@ -54,7 +54,11 @@ DEFER = os.environ.get("MILZMA_GEN_DEFER", "1") == "1"  # update a tree's probab
 JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"
 # pos_slot -> (distance base, jump target) through two per-lane constant tables instead of ~15 scalar instructions and
 # three branches per match
-TABLES = os.environ.get("MILZMA_GEN_TABLES", "1") == "1"  # enter the chain of direct bits with a computed jump instead of looping
+TABLES = os.environ.get("MILZMA_GEN_TABLES", "1") == "1"
+# GUARD1: one guard per match (rep0 >= gdist) and one per symbol top (len >= gtop): gdist is 0 while a match needs a closer
+# look (length >= 64, within 273 bytes of the output limit), gtop <= safe_len + 1, so the literal needs no limit test
+GUARD1 = os.environ.get("MILZMA_GEN_GUARD1", "1") == "1"
+NORM_INLINE = os.environ.get("MILZMA_GEN_NORM_INLINE", "0") == "1"  # normalisation inline, skipped by a short forward branch  # enter the chain of direct bits with a computed jump instead of looping
 PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
 # matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
 BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
@@ -92,7 +96,7 @@ RET = "s[92:93]"  # return address of the window refill subroutine
 V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
          vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
          VLANE192="v101", vb="v102", VSH6="v103", VSH6M1="v104", VSH5="v105", VSH5M1="v106", VSH4="v107",
-         VSH4M1="v108", VLEVEL="v109", va="v110", vr="v112")
+         VSH4M1="v108", VLEVEL="v109", va="v110", vr="v112", VLANEM1="v113")
 if PAD_V:
     V["vpad"] = "v111"
 MROW = "v[84:87]"
@@ -172,6 +176,25 @@ class Gen:
         """RangeDecoder::normalize (rangecoder.rs:59-69) as a check + out-of-line stub.
         `to`: label to continue at (default: fall through)."""
         k = self.new("N")
+        if NORM_INLINE:
+            skip = self.new("S")
+            self.e("s_cmp_lt_u32 {range}, 0x1000000")
+            self.e("s_cbranch_scc0 " + self.L(to if to is not None else skip))
+            self.e("s_cmp_eq_u32 {off}, {lim}")
+            self.e("s_cbranch_scc1 " + self.L("Xeof"))
+            self.e("v_readlane_b32 {n1}, {winb}, {off}")
+            self.e("s_lshl_b32 {range}, {range}, 8")
+            self.e("s_lshl_b32 {code}, {code}, 8")
+            self.e("s_or_b32 {code}, {code}, {n1}")
+            self.e("s_add_u32 {off}, {off}, 1")
+            self.e("s_bitcmp1_b32 {off}, 6")
+            self.e("s_cbranch_scc0 " + self.L(to if to is not None else skip))
+            self.e("s_call_b64 " + RET + ", " + self.L("refill"))
+            if to is not None:
+                self.e("s_branch " + self.L(to))
+            else:
+                self.lab(skip)
+            return
         if kind in NORM_S:
             self.e("s_cmp_lt_u32 {range}, 0x1000000")
             self.e("s_cbranch_scc1 " + self.L(k))
@@ -372,9 +395,8 @@ class Gen:
         e = self.e
         sh, shm1 = {6: ("VSH6", "VSH6M1"), 5: ("VSH5", "VSH5M1"), 4: ("VSH4", "VSH4M1")}[final_level]
         e("v_lshrrev_b32 {va}, {sh}, {sym}", sh=R(sh))
-        e("v_lshrrev_b32 {vx}, {sh}, {sym}", sh=R(shm1))
+        e("v_bfe_u32 {vx}, {sym}, {sh}, 1", sh=R(shm1))
         e("v_cmp_eq_u32 vcc, {va}, {v_lane}")
-        e("v_and_b32 {vx}, 1, {vx}")
         e("v_mad_u32_u24 {vx}, {vx}, {c2017}, 31")
         if min_level is not None:
             e("v_cmp_le_u32 " + MPAIR + ", {m}, {VLEVEL}", m=min_level)
@@ -432,17 +454,36 @@ class Gen:
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
 
+    def set_guards(self, t):
+        """gtop / gdist from len, lim, target, safe_len, mlen (prologue and window refill; clobbers SCC and t)"""
+        e = self.e
+        if not GUARD1:
+            e("s_cmpk_gt_u32 {lim}, 63")
+            e("s_cselect_b32 {gtop}, {target}, 0")
+            e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
+            return
+        e("s_add_u32 {t}, {safe_len}, 1", t=t)
+        e("s_min_u32 {gtop}, {target}, {t}", t=t)
+        e("s_cmpk_gt_u32 {lim}, 63")
+        e("s_cselect_b32 {gtop}, {gtop}, 0")
+        e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
+        e("s_cmpk_ge_u32 {mlen}, 64")
+        e("s_cselect_b32 {gdist}, 0, {gdist}")
+        e("s_cmp_gt_u32 {len}, {safe_len}")
+        e("s_cselect_b32 {gdist}, 0, {gdist}")
+
     def tables_prologue(self):
         """tbl_a[lane] / tbl_b[lane] for lane = the pos_slot walk's final symbol & 63 (the inverted path: slot = lane ^ 63):
         tbl_b = byte offset from Lbase of the code that continues this slot's distance (slots >= 14: the entry into the
         chain of 26 direct-bit blocks that leaves exactly (slot >> 1) - 5 of them to run; 4..13: dist_rev; < 4:
         dist_small); tbl_a = ((3 + (slot & 1)) << ndb) - 1 for slots >= 14 (what the inverted direct / align bits are
         subtracted from, lzma.rs:576-590), (2 | (slot & 1)) << ndb for 4..13, the slot itself below 4.
-        Computed once per unit (tbl_ready), the base address once per entry."""
+        Computed once per unit and loop variant (tbl_ready), the base address once per entry."""
         e, L = self.e, self.L
         e("s_getpc_b64 " + JBASE)
         self.lab("base")
-        e("s_cmp_lg_u32 {tbl_ready}, 0")
+        vid = 1 if self.lp0 else 2                          # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
+        e("s_cmp_eq_u32 {tbl_ready}, %d" % vid)             #  unit may change lp, and with it the variant, between chunks)
         e("s_cbranch_scc1 " + L("tbl_done"))
         bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
         e("v_xor_b32 {VT0}, 63, {v_lane}")                 # slot
@@ -475,7 +516,7 @@ class Gen:
         e("s_nop 0")
         e("s_nop 0")
         e("v_cndmask_b32 {tbl_a}, {tbl_a}, {VT0}, vcc")
-        e("s_mov_b32 {tbl_ready}, 1")
+        e("s_mov_b32 {tbl_ready}, %d" % vid)
         self.lab("tbl_done")
 
     def set_prio(self, reg, tmp):
@@ -540,12 +581,15 @@ class Gen:
             self.e("s_bitcmp1_b32 {sym}, 6")
             self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
             self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
+            self.lab(w + "_hfin")
             self.e("s_sub_u32 {mlen}, 0x211, {sym}")      # length = 18 + path = 18 + 255 - (sym - 256)
+            if GUARD1:
+                self.e("s_cmpk_ge_u32 {mlen}, 64")        # copies of 64 bytes and more are done outside the loop
+                self.e("s_cselect_b32 {gdist}, 0, {gdist}")
             self.e("s_branch " + self.L(done))
             self.lab(w + "_h3")
             self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
-            self.e("s_sub_u32 {mlen}, 0x211, {sym}")
-            self.e("s_branch " + self.L(done))
+            self.e("s_branch " + self.L(w + "_hfin"))
 
     def reverse_tree_based(self, T, base_reg, nbits, out):
         """parse_reverse_bit_tree (rangecoder.rs:136-151), node n at lane base + n"""
@@ -612,8 +656,19 @@ class Gen:
         self.decide(R("m_ismatch"), R("ln"), "match")
         with self.in_cold():
             lab("Otop_slow" + tag)
+            if GUARD1:
+                # a literal decoded at len == out_lim < target: append_literal's error (lzbuffer.rs:206-217); its store fell
+                # outside the slice or beyond out_len.  (len > out_lim >= target: a last match overshot the size, below.)
+                e("s_cmp_lt_u32 {out_lim}, {target}")
+                e("s_cbranch_scc0 " + L("Otop_size" + tag))
+                e("s_cmp_gt_u32 {len}, {out_lim}")
+                e("s_cbranch_scc1 " + L("Xlimit_undo"))
+                lab("Otop_size" + tag)
             e("s_cmp_ge_u32 {len}, {target}")
             e("s_cbranch_scc1 " + L("Xdone_size"))
+            if GUARD1:
+                e("s_cmp_gt_u32 {len}, {safe_len}")           # from here on every match looks closer
+                e("s_cselect_b32 {gdist}, 0, {gdist}")
             e("s_cmp_eq_u32 {off}, {lim}")                    # reader at EOF: the stream may be finished
             e("s_cbranch_scc0 " + L("top2" + tag))
             lab("Ofin_check" + tag)                           # unknown size: finished when the reader is at EOF
@@ -624,8 +679,9 @@ class Gen:
     def literal_epilogue(self):
         e, L = self.e, self.L
         e("s_xor_b32 {prev}, {sym}, 0x1ff")             # (0x100 | inverted path) -> byte
-        e("s_cmp_ge_u32 {len}, {out_lim}")
-        e("s_cbranch_scc1 " + L("Xlimit"))
+        if not GUARD1:
+            e("s_cmp_ge_u32 {len}, {out_lim}")
+            e("s_cbranch_scc1 " + L("Xlimit"))
         e("v_mov_b32 {VT0}, {prev}")
         e("v_or_b32 {VT1}, {len}, {VOOB}")
         if WAITPROF2:
@@ -767,6 +823,70 @@ class Gen:
             e("s_add_u32 {rep0}, {t2}, {t4}")
             e("s_branch " + L("copy"))
 
+    def copy_guards(self):
+        """the round-1 form: separate guards for the distance, the length and the output limit"""
+        e, lab, L = self.e, self.lab, self.L
+        e("s_add_u32 {t0}, {rep0}, 1")
+        e("s_cmp_ge_u32 {rep0}, {gdist}")                     # gdist <= min(len, dict_size): beyond it (and for the
+        e("s_cbranch_scc1 " + L("Ocopy_dist"))                # end marker, rep0 = 0xFFFFFFFF), look closer
+        lab("cp_dist_ok")
+        e("s_cmpk_ge_u32 {mlen}, 64")
+        e("s_cbranch_scc1 " + L("Xlz_slow"))
+        e("s_cmp_gt_u32 {len}, {safe_len}")                   # within 273 bytes of the output limit: look closer
+        e("s_cbranch_scc1 " + L("Ocopy_limit"))
+        lab("cp_lim_ok")
+        e("s_cmp_lg_u32 {pend_n}, 0")
+        e("s_cbranch_scc1 " + L("Opend_copy"))
+        lab("cp_a")
+        e("s_sub_u32 {t2}, {len}, {t0}")                      # src = pos - dist
+        e("s_cmp_le_u32 {t0}, {mlen}")
+        e("s_cbranch_scc1 " + L("Operiodic"))
+        e("v_add_u32 {VT0}, {t2}, {v_lane}")
+        lab("cp_b")
+        e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
+        e("s_mov_b32 {pend_pos}, {len}")
+        e("s_mov_b32 {pend_n}, {mlen}")
+        e("s_add_u32 {len}, {len}, {mlen}")
+        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        if WAITPROF2:
+            self.prof_begin()
+        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
+        if WAITPROF2:
+            self.prof_end("c")
+        e("s_branch " + L("topM"))
+
+    def copy_guard1(self):
+        """LzCircularBuffer::append_lz (lzbuffer.rs:255-281), short and unclipped: one guard, the previous match's store
+        completed inline (72 % of the matches of text follow a match), the load of this one issued"""
+        e, lab, L = self.e, self.lab, self.L
+        e("s_cmp_ge_u32 {rep0}, {gdist}")                     # gdist <= min(len, dict_size), 0 for long / late matches
+        e("s_cbranch_scc1 " + L("Ocopy_dist"))                # (the end marker, rep0 = 0xFFFFFFFF, goes there too)
+        lab("cp_lim_ok")
+        e("s_cmp_eq_u32 {pend_n}, 0")
+        e("s_cbranch_scc1 " + L("cp_a"))
+        e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
+        e("s_cbranch_scc1 " + L("Opend_clear"))
+        # (prev / mb are not taken from it: a match follows, and whatever symbol comes after that gets them
+        #  from that match's bytes)
+        self.finish_pending(prof="c", extract=False)
+        lab("cp_a")
+        e("s_sub_u32 {t2}, {len}, {rep0}")                    # src + 1 = pos - rep0
+        e("s_cmp_lt_u32 {rep0}, {mlen}")                      # dist <= n: the match overlaps itself
+        e("s_cbranch_scc1 " + L("Operiodic"))
+        e("v_add_u32 {VT0}, {t2}, {VLANEM1}")
+        lab("cp_b")
+        e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
+        e("s_mov_b32 {pend_pos}, {len}")
+        e("s_mov_b32 {pend_n}, {mlen}")
+        e("s_add_u32 {len}, {len}, {mlen}")
+        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        if WAITPROF2:
+            self.prof_begin()
+        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
+        if WAITPROF2:
+            self.prof_end("c")
+        e("s_branch " + L("topM"))
+
     def distance_tables(self):
         """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
         for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
@@ -845,9 +965,8 @@ class Gen:
         e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
         e("s_movk_i32 {c2017}, 2017")
         e("s_movk_i32 {c2048}, 0x800")
-        e("s_cmpk_gt_u32 {lim}, 63")
-        e("s_cselect_b32 {gtop}, {target}, 0")
-        e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
+        e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        self.set_guards(R("n0"))
         if TABLES:
             self.tables_prologue()
         if PRIO:
@@ -1064,38 +1183,17 @@ class Gen:
 
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
         lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
-        e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cmp_ge_u32 {rep0}, {gdist}")                     # gdist <= min(len, dict_size): beyond it (and for the
-        e("s_cbranch_scc1 " + L("Ocopy_dist"))                # end marker, rep0 = 0xFFFFFFFF), look closer
-        lab("cp_dist_ok")
-        e("s_cmpk_ge_u32 {mlen}, 64")
-        e("s_cbranch_scc1 " + L("Xlz_slow"))
-        e("s_cmp_gt_u32 {len}, {safe_len}")                   # within 273 bytes of the output limit: look closer
-        e("s_cbranch_scc1 " + L("Ocopy_limit"))
-        lab("cp_lim_ok")
-        e("s_cmp_lg_u32 {pend_n}, 0")
-        e("s_cbranch_scc1 " + L("Opend_copy"))
-        lab("cp_a")
-        e("s_sub_u32 {t2}, {len}, {t0}")                      # src = pos - dist
-        e("s_cmp_le_u32 {t0}, {mlen}")
-        e("s_cbranch_scc1 " + L("Operiodic"))
-        e("v_add_u32 {VT0}, {t2}, {v_lane}")
-        lab("cp_b")
-        e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
-        e("s_mov_b32 {pend_pos}, {len}")
-        e("s_mov_b32 {pend_n}, {mlen}")
-        e("s_add_u32 {len}, {len}, {mlen}")
-        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        if WAITPROF2:
-            self.prof_begin()
-        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
-        if WAITPROF2:
-            self.prof_end("c")
-        e("s_branch " + L("topM"))
+        if GUARD1:
+            self.copy_guard1()
+        else:
+            self.copy_guards()
 
         # ================= out-of-line helpers =================
         with self.in_cold():
             lab("Operiodic")                                  # source index = lane % dist (exact: lane < 64)
+            if GUARD1:
+                e("s_add_u32 {t0}, {rep0}, 1")
+                e("s_add_u32 {t2}, {t2}, -1")
             e("v_cvt_f32_u32 {VT1}, {t0}")
             e("v_rcp_f32 {VT1}, {VT1}")
             e("v_cvt_f32_u32 {VT2}, {v_lane}")
@@ -1111,11 +1209,21 @@ class Gen:
             if TABLES:                                        # (only a new distance can be the marker, lzma.rs:372-382: a
                 e("s_cmp_eq_u32 {rep0}, -1")                  #  rep never is, decoding stops at the first one)
                 e("s_cbranch_scc1 " + L("Xmarker"))
+            if GUARD1:
+                e("s_add_u32 {t0}, {rep0}, 1")
             e("s_cmp_gt_u32 {t0}, {dict_size}")
             e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
             e("s_cmp_gt_u32 {t0}, {len}")
             e("s_cbranch_scc1 " + L("Xlz_dist_out"))
-            e("s_branch " + L("cp_dist_ok"))
+            if GUARD1:
+                e("s_cmpk_ge_u32 {mlen}, 64")
+                e("s_cbranch_scc1 " + L("Xlz_slow"))
+                e("s_cmp_gt_u32 {len}, {safe_len}")           # within 273 bytes of the output limit
+                e("s_cbranch_scc1 " + L("Ocopy_limit"))
+                e("s_min_u32 {gdist}, {len}, {dict_size}")    # the bound was stale
+                e("s_branch " + L("cp_lim_ok"))
+            else:
+                e("s_branch " + L("cp_dist_ok"))
             lab("Ocopy_limit")                                # (the output resource starts at dict_base: pos = len)
             e("s_add_u32 {t2}, {len}, {mlen}")
             e("s_cbranch_scc1 " + L("Xlz_slow"))
@@ -1139,9 +1247,7 @@ class Gen:
             e("s_add_u32 {wbase}, {wbase}, 64")
             e("s_mov_b32 {off}, 0")
             e("s_sub_u32 {lim}, {lim}, 64")
-            e("s_cmpk_gt_u32 {lim}, 63")
-            e("s_cselect_b32 {gtop}, {target}, 0")
-            e("s_min_u32 {gdist}, {len}, {dict_size}")
+            self.set_guards(R("n0"))
             e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
@@ -1159,6 +1265,9 @@ class Gen:
             e("v_readfirstlane_b32 {mb}, {VT0}")
             e("s_branch " + L("lm_a"))
 
+            lab("Xlimit_undo")
+            e("s_add_u32 {len}, {len}, -1")
+            self.exit_with("LIMIT")
             for name, code in [("Xdone_size", "DONE_SIZE"), ("Xdone_fin", "DONE_FIN"), ("Xeof", "INPUT_EOF"),
                                ("Xmarker", "MARKER"), ("Xlimit", "LIMIT"), ("Xlz_slow", "LZ_SLOW"),
                                ("Xmatch_dist_dict", "MATCH_DIST_DICT"), ("Xmatch_dist_out", "MATCH_DIST_OUT"),
