@@ -72,6 +72,7 @@ PAD_B = int(os.environ.get("MILZMA_GEN_PAD_B", "0"))
 # with the youngest.  PRIO = k > 0: every window refill sets s_setprio ((len >> k) + wave slot) & 3, so that the four waves
 # of a SIMD take turns at every priority and finish together.  PRIO = -1: static priority = wave slot (diagnostic).
 PRIO = int(os.environ.get("MILZMA_GEN_PRIO", "12"))
+PRIO_TIME = int(os.environ.get("MILZMA_GEN_PRIO_TIME", "21"))  # k > 0: rotate on the shader clock ((s_memtime >> k) + slot) instead of on len
 # Decision "form B": range and code live in the adjacent pair s[66:67]; the vector ALU also delivers range - bound, both are
 # read into scalar pairs and ONE s_cselect_b64 picks (bound, code) or (range - bound, code - bound): 3 scalar + 5 vector
 # instructions and no wait state, against 5 + 3 + s_nop for form A.  Measured marginal cost (dead-instruction probes, r02):
@@ -884,8 +885,7 @@ class Gen:
             self.prof_begin()
         e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
         if WAITPROF2:
-            self.prof_end("c")
-        e("s_branch " + L("topM"))
+            self.prof_end("c")                               # falls through into the top after a match
 
     def distance_tables(self):
         """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
@@ -917,8 +917,7 @@ class Gen:
         e("s_brev_b32 {t3}, {t3}")                           # a'
         e("s_add_u32 {t4}, {t4}, {t3}")
         e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
-        e("s_branch " + L("copy"))
-        with self.in_cold():
+        with self.in_cold():                                 # falls through into `copy`
             lab("dist_small")
             e("s_mov_b32 {rep0}, {t2}")
             e("s_branch " + L("copy"))
@@ -1013,15 +1012,40 @@ class Gen:
         lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
         self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
         lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
-        e("s_bitcmp1_b32 {sym}, 6")
-        e("s_cbranch_scc1 " + L("plain7_hi"))
-        self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
+        e("s_bitcmp1_b32 {sym}, 6")          # (set for a byte with bit 7 clear: the fall-through serves ASCII)
+        e("s_cbranch_scc0 " + L("plain7_lo"))
+        self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
         lab("lit_done")
         self.literal_epilogue()
         with self.in_cold():
-            lab("plain7_hi")
-            self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
+            lab("plain7_lo")
+            self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
             self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
+
+        # Section order: a new match falls through its distance tail into `copy`, and `copy` into the top after a match, so that
+        # the only taken branches of a match are the computed jump into the direct bits and the loop's back edge.
+        # ================= match (lzma.rs:480-523) =================
+        lab("match")
+        self.taken(R("m_ismatch"))
+        self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
+        e("s_mov_b32 {rep3}, {rep2}")
+        e("s_mov_b32 {rep2}, {rep1}")
+        e("s_mov_b32 {rep1}, {rep0}")
+        self.len_decode(0, "len0_done")
+        e("s_cmpk_lt_u32 {state}, 7")
+        e("s_cselect_b32 {state}, 7, 10")
+        # ---- decode_distance (lzma.rs:563-592)
+        if TABLES:
+            self.distance_tables()
+        else:
+            self.distance_scalar()
+
+        # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
+        lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
+        if GUARD1:
+            self.copy_guard1()
+        else:
+            self.copy_guards()
 
         # ================= after a match =================
         self.symbol_top("M")
@@ -1117,22 +1141,6 @@ class Gen:
             lab("Oentry_fix")
             self.prev_fetch("topL")
 
-        # ================= match (lzma.rs:480-523) =================
-        lab("match")
-        self.taken(R("m_ismatch"))
-        self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
-        e("s_mov_b32 {rep3}, {rep2}")
-        e("s_mov_b32 {rep2}, {rep1}")
-        e("s_mov_b32 {rep1}, {rep0}")
-        self.len_decode(0, "len0_done")
-        e("s_cmpk_lt_u32 {state}, 7")
-        e("s_cselect_b32 {state}, 7, 10")
-        # ---- decode_distance (lzma.rs:563-592)
-        if TABLES:
-            self.distance_tables()
-        else:
-            self.distance_scalar()
-
         # ---- rep matches (lzma.rs:483-509)
         lab("rep_match")
         self.taken(R("m_rep"))
@@ -1180,13 +1188,7 @@ class Gen:
         self.len_decode(1, "len1_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 8, 11")
-
-        # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
-        lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
-        if GUARD1:
-            self.copy_guard1()
-        else:
-            self.copy_guards()
+        e("s_branch " + L("copy"))
 
         # ================= out-of-line helpers =================
         with self.in_cold():
@@ -1251,7 +1253,13 @@ class Gen:
             e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
-            if PRIO > 0:
+            if PRIO > 0 and PRIO_TIME:
+                e("s_memtime s[94:95]")
+                e("s_waitcnt lgkmcnt(0)")
+                e("s_lshr_b64 s[94:95], s[94:95], %d" % PRIO_TIME)
+                e("s_add_u32 {n1}, s94, {prioph}")
+                self.set_prio(R("n1"), R("n0"))
+            elif PRIO > 0:
                 e("s_lshr_b32 {n1}, {len}, %d" % PRIO)       # (n0 / n1: the only temporaries free wherever a refill happens)
                 e("s_add_u32 {n1}, {n1}, {prioph}")
                 self.set_prio(R("n1"), R("n0"))
