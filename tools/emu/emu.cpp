@@ -34,7 +34,7 @@ struct Ins {
   X(s_mov_b32) X(s_movk_i32) X(s_not_b32) X(s_brev_b32) X(s_add_u32) X(s_addc_u32) X(s_sub_u32) X(s_subb_u32)          \
   X(s_and_b32) X(s_or_b32) X(s_xor_b32) X(s_andn2_b32) X(s_lshl_b32) X(s_lshr_b32) X(s_ashr_i32) X(s_min_u32)          \
   X(s_max_u32) X(s_max_i32) X(s_min_i32) X(s_mul_i32) X(s_cselect_b32) X(s_cselect_b64) X(s_lshl2_add_u32)             \
-  X(s_lshl1_add_u32) X(s_lshl3_add_u32) X(s_and_b64) X(s_or_b64) X(s_mov_b64) X(s_lshl_b64) X(s_bfe_u32)               \
+  X(s_lshl1_add_u32) X(s_lshl3_add_u32) X(s_and_b64) X(s_or_b64) X(s_mov_b64) X(s_lshl_b64) X(s_lshr_b64) X(s_bfe_u32)               \
   X(s_bfm_b32) X(s_flbit_i32_b32) X(s_ff1_i32_b32) X(s_ff1_i32_b64) X(s_bcnt1_i32_b32) X(s_cmp_eq_u32)                 \
   X(s_cmp_lg_u32) X(s_cmp_gt_u32) X(s_cmp_ge_u32) X(s_cmp_lt_u32) X(s_cmp_le_u32) X(s_cmp_lt_i32) X(s_cmp_gt_i32)      \
   X(s_cmpk_eq_u32) X(s_cmpk_lg_u32) X(s_cmpk_gt_u32) X(s_cmpk_ge_u32) X(s_cmpk_lt_u32) X(s_cmpk_le_u32)                \
@@ -213,6 +213,7 @@ long run(Emu& e, int start, long max_steps) {
       case OP_s_or_b64: { uint64_t r = rs64(e, I.a[1]) | rs64(e, I.a[2]); ws64(e, I.a[0], r); e.scc = r != 0; } break;
       case OP_s_lshl_b32: { uint32_t r = rs(e, I.a[1]) << (rs(e, I.a[2]) & 31u); ws(e, I.a[0], r); e.scc = r != 0; } break;
       case OP_s_lshl_b64: { uint64_t r = rs64(e, I.a[1]) << (rs(e, I.a[2]) & 63u); ws64(e, I.a[0], r); e.scc = r != 0; } break;
+      case OP_s_lshr_b64: { uint64_t r = rs64(e, I.a[1]) >> (rs(e, I.a[2]) & 63u); ws64(e, I.a[0], r); e.scc = r != 0; } break;
       case OP_s_lshr_b32: { uint32_t r = rs(e, I.a[1]) >> (rs(e, I.a[2]) & 31u); ws(e, I.a[0], r); e.scc = r != 0; } break;
       case OP_s_ashr_i32: { uint32_t r = uint32_t(int32_t(rs(e, I.a[1])) >> (rs(e, I.a[2]) & 31u)); ws(e, I.a[0], r); e.scc = r != 0; } break;
       case OP_s_min_u32: { uint32_t a = rs(e, I.a[1]), b = rs(e, I.a[2]); ws(e, I.a[0], a < b ? a : b); e.scc = a < b; } break;
