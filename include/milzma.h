@@ -120,12 +120,18 @@ const char *milzma_last_error(const milzma_ctx *ctx);
  *   results      host array of n results
  *   hip_stream   hipStream_t to launch on (NULL = default stream); the call returns after the
  *                results have been copied back (it synchronises that stream)
- * Returns MILZMA_OK or MILZMA_INFRA_ERROR; per-unit failures never fail the batch. */
+ * Returns MILZMA_OK or MILZMA_INFRA_ERROR; per-unit failures never fail the batch.
+ * Addressing: a unit reads d_in[in_off, in_off + in_len) and owns d_out[out_off, out_off + out_cap); output slices
+ * must not overlap.  The kernels fetch the input in aligned 64-byte (256-byte for the generic kernel) windows, so up
+ * to 255 bytes before the first and after the last unit's input may be READ (never used): d_in must come from an
+ * allocation that extends that far (any hipMalloc'd buffer does at the front; leave 256 bytes of slack at the end,
+ * as milzma_decode_units_host does).  A RAW unit's dict_size below 4096 is raised to 4096 (lzma.rs:118-120). */
 int milzma_decode_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_in,
                         void *d_out, milzma_result *results, void *hip_stream);
 
 /* Same, with host-resident input / output: the library stages both through device buffers it
- * owns (PCIe-inclusive path). */
+ * owns (PCIe-inclusive path).  Every unit's slices are checked against in_bytes / out_bytes and
+ * against each other (MILZMA_INFRA_ERROR, nothing decoded, if one lies outside or two outputs overlap). */
 int milzma_decode_units_host(milzma_ctx *ctx, const milzma_unit *units, uint32_t n,
                              const void *h_in, size_t in_bytes, void *h_out, size_t out_bytes,
                              milzma_result *results);
@@ -203,6 +209,17 @@ int milzma_crc_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, cons
  * message in `out` (kind/msg only) on failure. */
 int milzma_lzma_read_header(const uint8_t *in, size_t in_len, const milzma_options *opt,
                             milzma_unit *unit, size_t *header_len, milzma_output *out);
+
+/* Footer + Index of a well-formed .xz file (src/decode/xz.rs:35-110 read in the other direction) -> one
+ * MILZMA_KIND_LZMA2 unit per block, for pipelines that keep files and output in device memory: in_off /
+ * in_len locate the block's LZMA2 payload relative to the file's first byte, out_cap = unpacked_size = the
+ * Index's uncompressed size, out_off packs the outputs from 0 (256-byte aligned).  *n_units = blocks in
+ * the file (also when `units` is NULL or `cap` too small: MILZMA_INFRA_ERROR then); *check_id = the
+ * stream's check type (0 none, 1 CRC32, 4 CRC64).  MILZMA_XZ_ERROR if the Index cannot be used (the
+ * whole-file entry points then still give the reference's verdict).  Container integrity (header / index /
+ * footer CRCs, the blocks' check values) is NOT verified here. */
+int milzma_xz_plan(const uint8_t *in, size_t in_len, milzma_unit *units, uint32_t cap,
+                   uint32_t *n_units, uint32_t *check_id);
 
 /* CRC-32 (ISO-HDLC) and CRC-64/XZ as used by the XZ layer (src/xz/crc.rs:1-4). */
 uint32_t milzma_crc32(const uint8_t *p, size_t n);

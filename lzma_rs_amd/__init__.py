@@ -137,7 +137,7 @@ EXPORTS = [
     "milzma_result_message", "milzma_default_options", "milzma_free",
     "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
     "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
-    "milzma_lzma_read_header", "milzma_crc32", "milzma_crc64",
+    "milzma_lzma_read_header", "milzma_crc32", "milzma_crc64", "milzma_xz_plan",
 ]
 
 _lib = None
@@ -186,6 +186,7 @@ def lib():
                                              ctypes.POINTER(_COutput)]
     L.milzma_lzma_read_header.argtypes = [vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(Unit),
                                           ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
+    L.milzma_xz_plan.argtypes = [vp, sz, ctypes.POINTER(Unit), u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.milzma_crc32.restype = u32
     L.milzma_crc32.argtypes = [vp, sz]
     L.milzma_crc64.restype = u64
@@ -408,6 +409,19 @@ def lzma_read_header(data, options=None):
     if kind != OK:
         raise _ERRORS[kind](out.msg.decode())
     return u, hl.value
+
+
+def xz_plan(data):
+    """One LZMA2 Unit per block of a well-formed .xz file (offsets relative to the file) and the check id,
+    or raises XzError when the file's Index cannot be used."""
+    p, n, keep = _as_buffer(data)
+    cnt, chk = ctypes.c_uint32(), ctypes.c_uint32()
+    if lib().milzma_xz_plan(p, n, None, 0, ctypes.byref(cnt), ctypes.byref(chk)) == XZ_ERROR:
+        raise XzError("xz error: the file's index cannot be used to plan its blocks")
+    units = (Unit * max(cnt.value, 1))()
+    if lib().milzma_xz_plan(p, n, units, cnt.value, ctypes.byref(cnt), ctypes.byref(chk)) != OK:
+        raise XzError("xz error: the file's index cannot be used to plan its blocks")
+    return [units[i] for i in range(cnt.value)], chk.value
 
 
 def crc32(data):

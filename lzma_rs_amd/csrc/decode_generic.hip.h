@@ -367,7 +367,7 @@ struct GenericDecoder {
         rep0 = decode_distance(mlen);
         if (eof) return fail(MILZMA_ST_INPUT_EOF), false;
         if (rep0 == 0xFFFFFFFFu) {  // end-of-stream marker (lzma.rs:372-382)
-          if (code == 0 && reader_eof(rd)) return true;
+          if (code == 0 && reader_eof(rd)) break;  // Finished: the known-size check below still applies (lzma.rs:513-521)
           return fail(MILZMA_ST_MARKER_TRAILING), false;
         }
       }

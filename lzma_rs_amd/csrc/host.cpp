@@ -53,10 +53,8 @@ struct milzma_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
   uint32_t last_launches = 0;
-  // MILZMA_KERNEL (A/B runs, tests): "generic" turns the lane-resident-model kernels off, "fast" picks the
-  // one whose symbol loop is C++, "asm" (default) the one whose symbol loop is hand-scheduled asm.
+  // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
-  int fast_variant = 1;
 };
 
 namespace {
@@ -153,7 +151,6 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   ctx->device = device;
   if (const char* k = getenv("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
-    ctx->fast_variant = strcmp(k, "fast") == 0 ? 0 : 1;
   }
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
       !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
@@ -229,7 +226,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
-    const hipError_t le = cls == kFast ? launch_fast(ctx->fast_variant, d_units, d_order + i, m, d_in, d_out, d_results, stream)
+    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream)
                                        : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
@@ -245,7 +242,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
 
 }  // namespace
 
-extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
+static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
                                    void* d_out, milzma_result* results, void* hip_stream) {
   if (!ctx) return MILZMA_INFRA_ERROR;
   ctx->last_ms = 0.f;
@@ -257,6 +254,15 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
   }
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  // LzmaParams::read_header raises a dictionary below 4 KiB to 4 KiB (lzma.rs:118-120); a RAW unit built by hand gets
+  // the same floor (the kernels divide by dict_size).
+  std::vector<milzma_unit> fixed;
+  for (uint32_t i = 0; i < n; i++)
+    if (units[i].kind == MILZMA_KIND_RAW_LZMA && units[i].dict_size < 0x1000u) {
+      if (fixed.empty()) fixed.assign(units, units + n);
+      fixed[i].dict_size = 0x1000u;
+    }
+  if (!fixed.empty()) units = fixed.data();
 
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
@@ -319,9 +325,29 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
   return MILZMA_OK;
 }
 
-extern "C" int milzma_decode_units_host(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
+static int milzma_decode_units_host_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
                                         size_t in_bytes, void* h_out, size_t out_bytes, milzma_result* results) {
   if (!ctx) return MILZMA_INFRA_ERROR;
+  // the kernels address input and output through the descriptors alone: a slice outside the buffers the caller
+  // described, or two output slices that overlap, would be out-of-bounds device accesses
+  {
+    std::vector<std::pair<uint64_t, uint64_t>> spans;
+    spans.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+      const milzma_unit& u = units[i];
+      if (u.in_off > in_bytes || u.in_len > in_bytes - u.in_off || u.out_off > out_bytes || u.out_cap > out_bytes - u.out_off) {
+        ctx->err = "unit " + std::to_string(i) + ": input or output slice outside the buffers";
+        return MILZMA_INFRA_ERROR;
+      }
+      if (u.out_cap) spans.emplace_back(u.out_off, u.out_off + u.out_cap);
+    }
+    std::sort(spans.begin(), spans.end());
+    for (size_t k = 1; k < spans.size(); k++)
+      if (spans[k].first < spans[k - 1].second) {
+        ctx->err = "overlapping output slices";
+        return MILZMA_INFRA_ERROR;
+      }
+  }
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
   if (!dev_reserve(ctx, ctx->in, in_bytes + 512) || !dev_reserve(ctx, ctx->out, out_bytes + 512)) return MILZMA_INFRA_ERROR;
   if (in_bytes && !hip_ok(ctx, hipMemcpy(ctx->in.p, h_in, in_bytes, hipMemcpyHostToDevice), "H2D input"))
@@ -652,6 +678,7 @@ int infra(milzma_ctx* ctx, milzma_output* o) {
 }
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+size_t plan_budget(milzma_ctx* ctx);
 
 // One unit through the device with host buffers, growing the output slice while the kernel
 // reports OUT_FULL.  `cap_hint` is the first slice size to try.
@@ -668,10 +695,25 @@ bool decode_single(milzma_ctx* ctx, milzma_unit u, const uint8_t* in, size_t in_
     u.in_len = in_len;
     u.out_off = 0;
     u.out_cap = cap;
-    sd->out.resize(cap);
-    if (milzma_decode_units_host(ctx, &u, 1, in, in_len, sd->out.data(), cap, &sd->res) != MILZMA_OK) return false;
-    if (sd->res.status != MILZMA_ST_OUT_FULL || cap >= MILZMA_MAX_UNIT_BYTES) return true;
-    cap = cap * 4;
+    if (!ctx) return false;
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !dev_reserve(ctx, ctx->in, in_len + 512) ||
+        !dev_reserve(ctx, ctx->out, cap + 512))
+      return false;
+    if (in_len && !hip_ok(ctx, hipMemcpy(ctx->in.p, in, in_len, hipMemcpyHostToDevice), "H2D input")) return false;
+    if (milzma_decode_units(ctx, &u, 1, ctx->in.p, ctx->out.p, &sd->res, nullptr) != MILZMA_OK) return false;
+    if (sd->res.status == MILZMA_ST_OUT_FULL && cap < MILZMA_MAX_UNIT_BYTES) {
+      cap = cap * 4;
+      continue;
+    }
+    const size_t got = size_t(std::min<uint64_t>(sd->res.out_len, cap));  // only what was decoded travels back
+    try {
+      sd->out.resize(got);
+    } catch (const std::bad_alloc&) {
+      ctx->err = "out of host memory for a decoded stream";
+      return false;
+    }
+    if (got && !hip_ok(ctx, hipMemcpy(sd->out.data(), ctx->out.p, got, hipMemcpyDeviceToHost), "D2H output")) return false;
+    return true;
   }
 }
 
@@ -731,11 +773,15 @@ extern "C" int milzma_lzma_read_header(const uint8_t* in, size_t in_len, const m
 
 namespace {
 
-// slice size to try first for a RAW unit
+// Slice size to try first for a RAW unit.  The declared size comes from the (untrusted) header: it is only believed up to
+// what the payload could plausibly expand to; a stream that really is denser goes through the OUT_FULL regrow rounds.
+// A memlimit below the dictionary size ends the stream at memlimit bytes (lzbuffer.rs:206-217).
 size_t lzma_cap_hint(const milzma_unit& u, size_t payload_len) {
-  if (u.unpacked_size != MILZMA_SIZE_UNKNOWN)
-    return size_t(std::min<uint64_t>(u.unpacked_size, MILZMA_MAX_UNIT_BYTES - 512)) + 288;  // + one overshooting match
-  return std::max<size_t>(1 << 16, payload_len * 6);
+  const uint64_t plausible = std::max<uint64_t>(uint64_t(1) << 20, uint64_t(payload_len) * 1024);
+  uint64_t cap = std::max<uint64_t>(1 << 16, uint64_t(payload_len) * 6);
+  if (u.unpacked_size != MILZMA_SIZE_UNKNOWN) cap = std::min<uint64_t>(u.unpacked_size, plausible) + 288;  // + one overshooting match
+  if (u.memlimit < uint64_t(u.dict_size)) cap = std::min<uint64_t>(cap, u.memlimit + 288);
+  return size_t(std::min<uint64_t>(cap, MILZMA_MAX_UNIT_BYTES - 512));
 }
 
 // Turns a finished RAW/LZMA2 unit into what the caller's writer / reader saw.
@@ -750,7 +796,7 @@ int finish_stream(const milzma_result& r, uint32_t kind, const uint8_t* slice, s
 
 }  // namespace
 
-extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const milzma_options* opt,
+static int milzma_lzma_decompress_impl(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const milzma_options* opt,
                                       milzma_output* out) {
   milzma_unit u;
   size_t hl = 0;
@@ -761,7 +807,7 @@ extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t
   return finish_stream(sd.res, MILZMA_KIND_RAW_LZMA, sd.out.data(), sd.out.size(), hl, out);
 }
 
-extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
+static int milzma_lzma2_decompress_impl(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
   out_reset(out);
   milzma_unit u;
   memset(&u, 0, sizeof u);
@@ -779,6 +825,14 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   std::vector<milzma_unit> units;
   std::vector<uint32_t> owner;  // unit -> stream
   std::vector<size_t> hdr(n, 0);
+  std::vector<uint32_t> alone;  // streams decoded one at a time
+  const size_t budget = plan_budget(ctx);
+  const auto single = [&](uint32_t i) {
+    if (lzma2)
+      milzma_lzma2_decompress(ctx, ins[i], in_lens[i], &outs[i]);
+    else
+      milzma_lzma_decompress(ctx, ins[i], in_lens[i], opt, &outs[i]);
+  };
   size_t in_total = 0, out_total = 0;
   for (uint32_t i = 0; i < n; i++) {
     out_reset(&outs[i]);
@@ -799,22 +853,32 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     u.out_off = out_total;
     u.out_cap = std::min<size_t>(round_up(lzma2 ? std::max<size_t>(1 << 16, payload * 6) : lzma_cap_hint(u, payload), 256),
                                  MILZMA_MAX_UNIT_BYTES);
+    if (in_total + out_total + round_up(payload, 256) + u.out_cap > budget) {  // on its own, after the batch
+      alone.push_back(i);
+      continue;
+    }
     in_total += round_up(payload, 256);
     out_total += u.out_cap;
     units.push_back(u);
     owner.push_back(i);
   }
-  if (units.empty()) return MILZMA_OK;
+  const auto finish_alone = [&]() {
+    for (uint32_t i : alone) single(i);
+    return MILZMA_OK;
+  };
+  if (units.empty()) return finish_alone();
   // page-locked staging (PCIe at link speed), filled and emptied by several host threads
   auto fail_all = [&]() {
     for (uint32_t i : owner) infra(ctx, &outs[i]);
     return MILZMA_INFRA_ERROR;
   };
   if (!ctx) return fail_all();
-  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !pin_reserve(ctx, ctx->pin_in, in_total) ||
-      !pin_reserve(ctx, ctx->pin_out, out_total) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
-      !dev_reserve(ctx, ctx->out, out_total + 512))
-    return fail_all();
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail_all();
+  if (!pin_reserve(ctx, ctx->pin_in, in_total) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
+      !dev_reserve(ctx, ctx->in, in_total + 512) || !dev_reserve(ctx, ctx->out, out_total + 512)) {
+    for (uint32_t i : owner) single(i);  // the batch's staging cannot be had: one stream at a time
+    return finish_alone();
+  }
   uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
   parallel_for(units.size(), [&](size_t k) {
     memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
@@ -859,17 +923,17 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       }
     todo.swap(next);
   }
-  return MILZMA_OK;
+  return finish_alone();
 }
 
 }  // namespace
 
-extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+static int milzma_lzma_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                             const milzma_options* opt, milzma_output* outs) {
   return stream_batch(ctx, n, ins, in_lens, opt, false, outs);
 }
 
-extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+static int milzma_lzma2_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                              milzma_output* outs) {
   return stream_batch(ctx, n, ins, in_lens, nullptr, true, outs);
 }
@@ -1216,6 +1280,15 @@ size_t check_size(int check) {
   }
 }
 
+// Bytes of staging (input + output) the batch paths may plan ahead for: MILZMA_PLAN_BUDGET (bytes), else three quarters
+// of the device memory that is free right now.
+size_t plan_budget(milzma_ctx* ctx) {
+  if (const char* e = getenv("MILZMA_PLAN_BUDGET")) return size_t(strtoull(e, nullptr, 0));
+  size_t free_b = 0, total_b = 0;
+  if (!ctx || hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return size_t(1) << 32;
+  return free_b / 4 * 3 + ctx->in.cap + ctx->out.cap;
+}
+
 // Best-effort parse of footer + Index.  Any oddity => false (the exact walk then decodes on
 // demand and reports whatever the reference would).
 bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blocks) {
@@ -1247,6 +1320,10 @@ bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blo
     const size_t hsize = (size_t(hsize_byte) + 1) << 2;  // whole header incl. size byte and CRC32
     if (uint64_t(hsize) + check_size(check) > unpadded) return false;
     if (unpacked > MILZMA_MAX_UNIT_BYTES) return false;
+    // An LZMA2 chunk is at least 11 bytes (6 header + 5 range-coder init) and yields at most 2 MiB: an Index that promises
+    // more than that per payload byte is wrong, and believing it would reserve memory for it.
+    const uint64_t payload = unpadded - hsize - check_size(check);
+    if (unpacked > (payload / 11 + 1) * (uint64_t(2) << 20)) return false;
     blocks->push_back(PlannedBlock{pos + hsize, size_t(unpadded) - hsize - check_size(check), unpacked});
     pos += size_t((unpadded + 3) & ~uint64_t(3));
   }
@@ -1255,7 +1332,7 @@ bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blo
 
 }  // namespace
 
-extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                           milzma_output* outs) {
   if (!ctx) return MILZMA_INFRA_ERROR;
   // 1. plan: every block the Index of a file names becomes one LZMA2 unit of a single launch
@@ -1268,9 +1345,13 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
   size_t in_total = 0, out_total = 0;
   std::vector<size_t> file_in_off(n, 0), file_out_hint(n, 0);
   std::vector<uint8_t> planned(n, 0);
+  const size_t budget = plan_budget(ctx);
   for (uint32_t i = 0; i < n; i++) {
     std::vector<PlannedBlock> blocks;
     if (!plan_from_index(ins[i], in_lens[i], &blocks)) continue;
+    size_t need = round_up(in_lens[i], 256);
+    for (const auto& b : blocks) need += round_up(size_t(b.unpacked) + 16, 256);
+    if (in_total + out_total + need > budget) continue;  // decoded on demand by the walk instead
     file_in_off[i] = in_total;
     for (const auto& b : blocks) {
       milzma_unit u;
@@ -1298,36 +1379,33 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
   const uint8_t* hout = nullptr;
   const uint8_t* parts = nullptr;
   if (nu) {
-    auto fail_all = [&]() {
-      for (uint32_t i = 0; i < n; i++) {
-        out_reset(&outs[i]);
-        infra(ctx, &outs[i]);
-      }
-      return MILZMA_INFRA_ERROR;
+    // Decoding ahead is an optimisation: if its memory cannot be had (or anything else goes wrong here) the walk below
+    // decodes every block on demand and each file still gets the reference's verdict.
+    const auto ahead = [&]() -> bool {
+      if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return false;
+      const size_t parts_bytes = size_t(nu) * kCrcPartsBytes;
+      if (!pin_reserve(ctx, ctx->pin_in, in_total) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
+          !pin_reserve(ctx, ctx->pin_small, parts_bytes) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
+          !dev_reserve(ctx, ctx->out, out_total + 512) || !dev_reserve(ctx, ctx->crc, parts_bytes))
+        return false;
+      uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
+      parallel_for(n, [&](size_t i) {
+        if (planned[i]) memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
+      });
+      if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return false;
+      if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK) return false;
+      // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
+      return hip_ok(ctx,
+                    launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
+                                     static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, nullptr),
+                    "crc kernel launch") &&
+             hip_ok(ctx, hipMemcpy(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost), "D2H crc parts") &&
+             hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output");
     };
-    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail_all();
-    const size_t parts_bytes = size_t(nu) * kCrcPartsBytes;
-    if (!pin_reserve(ctx, ctx->pin_in, in_total) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
-        !pin_reserve(ctx, ctx->pin_small, parts_bytes) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
-        !dev_reserve(ctx, ctx->out, out_total + 512) || !dev_reserve(ctx, ctx->crc, parts_bytes))
-      return fail_all();
-    uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-    parallel_for(n, [&](size_t i) {
-      if (planned[i]) memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
-    });
-    if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return fail_all();
-    if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK)
-      return fail_all();
-    // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
-    if (!hip_ok(ctx,
-                launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
-                                 static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, nullptr),
-                "crc kernel launch") ||
-        !hip_ok(ctx, hipMemcpy(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost), "D2H crc parts") ||
-        !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output"))
-      return fail_all();
-    hout = static_cast<const uint8_t*>(ctx->pin_out.p);
-    parts = static_cast<const uint8_t*>(ctx->pin_small.p);
+    if (ahead()) {
+      hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+      parts = static_cast<const uint8_t*>(ctx->pin_small.p);
+    }
   }
   // 3. the reference's walk per file (files in parallel on the host); a payload decoded ahead is used only
   //    if it is provably what an unlimited reader would have produced (clean status, consumed exactly the
@@ -1371,4 +1449,108 @@ extern "C" int milzma_xz_decompress(milzma_ctx* ctx, const uint8_t* in, size_t i
   const size_t lens[1] = {in_len};
   const int r = milzma_xz_decompress_batch(ctx, 1, ins, lens, out);
   return r != MILZMA_OK ? r : out->kind;
+}
+
+extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
+                                   void* d_out, milzma_result* results, void* hip_stream) {
+  try {
+    return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_decode_units_host(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
+                                        size_t in_bytes, void* h_out, size_t out_bytes, milzma_result* results) {
+  try {
+    return milzma_decode_units_host_impl(ctx, units, n, h_in, in_bytes, h_out, out_bytes, results);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const milzma_options* opt,
+                                      milzma_output* out) {
+  try {
+    return milzma_lzma_decompress_impl(ctx, in, in_len, opt, out);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    if (out) out_fail(out, MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
+  try {
+    return milzma_lzma2_decompress_impl(ctx, in, in_len, out);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    if (out) out_fail(out, MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                            const milzma_options* opt, milzma_output* outs) {
+  try {
+    return milzma_lzma_decompress_batch_impl(ctx, n, ins, in_lens, opt, outs);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                             milzma_output* outs) {
+  try {
+    return milzma_lzma2_decompress_batch_impl(ctx, n, ins, in_lens, outs);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                          milzma_output* outs) {
+  try {
+    return milzma_xz_decompress_batch_impl(ctx, n, ins, in_lens, outs);
+  } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+// Index of a well-formed .xz file -> one LZMA2 unit per block (offsets relative to the file's first byte, out_off / out_cap
+// packed from 0 in file order): what milzma_xz_decompress_batch decodes ahead, for callers that keep files and
+// output in device memory (bench.py --config xz).  The container checks (header / index / footer CRCs, block check
+// values via milzma_crc_units) remain the caller's; the whole-file entry points do all of it.
+extern "C" int milzma_xz_plan(const uint8_t* in, size_t in_len, milzma_unit* units, uint32_t cap, uint32_t* n_units,
+                              uint32_t* check_id) {
+  try {
+    std::vector<PlannedBlock> blocks;
+    if (!in || !n_units || !plan_from_index(in, in_len, &blocks)) return MILZMA_XZ_ERROR;
+    *n_units = uint32_t(blocks.size());
+    if (check_id) *check_id = in[in_len - 3];  // stream flags, second byte (footer copy)
+    if (!units || cap < blocks.size()) return blocks.size() > cap ? MILZMA_INFRA_ERROR : MILZMA_OK;
+    uint64_t out = 0;
+    for (size_t k = 0; k < blocks.size(); k++) {
+      milzma_unit& u = units[k];
+      memset(&u, 0, sizeof u);
+      u.kind = MILZMA_KIND_LZMA2;
+      u.in_off = blocks[k].data_off;
+      u.in_len = blocks[k].data_len;
+      u.out_off = out;
+      u.out_cap = blocks[k].unpacked;
+      u.unpacked_size = blocks[k].unpacked;
+      out += round_up(size_t(blocks[k].unpacked), 256);
+    }
+    return MILZMA_OK;
+  } catch (const std::exception&) {
+    return MILZMA_INFRA_ERROR;
+  }
 }

@@ -2,7 +2,6 @@
 #include "kernels.h"
 
 #include "decode_generic.hip.h"
-#include "decode_fast.hip.h"
 #include "decode_fast_asm.hip.h"
 #include "crc_units.hip.h"
 
@@ -36,15 +35,10 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
   return hipGetLastError();
 }
 
-hipError_t launch_fast(int variant, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
-                       const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, hipStream_t stream) {
+hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
+                       milzma_result* d_results, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  if (variant == 1)
-    hipLaunchKernelGGL(decode_fast_asm_kernel, dim3(n), dim3(kWave), 0, stream, d_units, d_order, n, d_in, d_out,
-                       d_results);
-  else
-    hipLaunchKernelGGL(decode_fast_kernel, dim3(n), dim3(kWave), 0, stream, d_units, d_order, n, d_in, d_out,
-                       d_results);
+  hipLaunchKernelGGL(decode_fast_asm_kernel, dim3(n), dim3(kWave), 0, stream, d_units, d_order, n, d_in, d_out, d_results);
   return hipGetLastError();
 }
 

@@ -84,3 +84,17 @@ def test_emulated_loop_output_limit(loops, kind):
         r = loops[True].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=cap)
         assert r["status"] == "OUT_FULL", (cap, r["status"])
         assert r["len"] == cap and r["out"] == plain[:cap]
+
+
+def test_marker_before_a_declared_size(loops):
+    """a stream that ends with the marker before the size its header declares: Finished by the marker
+    (lzma.rs:372-377), then the known-size check after the loop fails it (lzma.rs:513-521)"""
+    plain = W.make_plain("text", 5000, seed=3)
+    comp = W.compress_alone(plain, dict_size=65536, known_size=False)
+    for declared in (5001, 6000, 1 << 32, 1 << 40):
+        lie = comp[:5] + struct.pack("<Q", declared) + comp[13:]
+        ref = orc.lzma_decompress(lie)
+        assert ref.msg == "lzma error: Expected unpacked size of %d but decompressed to 5000" % declared
+        lc, lp, pb, ds, us = _hdr(lie)
+        r = loops[True].decode_raw(lie[13:], lc, lp, pb, ds, us, out_cap=8192)
+        assert r["status"] == "SIZE_MISMATCH" and r["len"] == 5000 and r["in_consumed"] + 13 == ref.in_consumed

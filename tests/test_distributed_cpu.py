@@ -85,3 +85,29 @@ def test_two_ranks_gloo():
         assert p.exitcode == 0
     for rank, t, total, n, ok in res:
         assert t == 2.0 and total == 30.0 and n == 100 + 50 * rank and ok
+
+
+def test_bench_rank_logic_two_ranks_gloo():
+    """bench.py's multi-rank path up to (not including) the first decode, world size 2 over gloo on CPU: generation
+    per rank, process-group rendezvous, input scatter, barrier and the max-over-ranks / sum-over-ranks reductions."""
+    import json
+    import subprocess
+    env = dict(os.environ, MILZMA_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--scatter", "--streams", "8",
+                        "--size", "65536", "--distinct", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["units_all_ranks"] == 16 and line["max_time"] == 0.002
+
+
+def test_bench_refuses_more_gpus_than_present():
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("MILZMA_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2)], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -370,6 +370,8 @@ class AsmLoop:
             elif name == "MARKER":
                 rem = self.sget("lim") - self.sget("off")
                 status = ST_OK if (rem == 0 and self.sget("code") == 0) else "MARKER_TRAILING"
+                if status == ST_OK and known and ln != unpacked_size:   # lzma.rs:513-521 applies after the marker too
+                    status = "SIZE_MISMATCH"
             elif name == "LIMIT":
                 status = "OUT_FULL"
             else:

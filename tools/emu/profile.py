@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dict", type=int, default=1 << 16)
     ap.add_argument("--regions", type=int, default=0)
     ap.add_argument("--index", type=int, default=0)
+    ap.add_argument("--json", default="", help="also write the mix to this file (bench.py reads profiles/r02_instruction_mix.json)")
     a = ap.parse_args()
     plain = W.make_plain(a.kind, a.size, seed=W.SEED0 ^ a.index)
     comp = W.compress_alone(plain, dict_size=a.dict, known_size=True)
@@ -42,6 +43,17 @@ def main():
     print("%s %d B, dict %d: compressed %d B, %d instructions executed (%.1f s), bit-exact"
           % (a.kind, a.size, a.dict, len(comp) - 13, r["executed"], time.time() - t))
     print("per output byte: " + "  ".join("%s %.2f" % (k, mix[k] / n) for k in ("salu", "valu", "branch", "misc", "lds", "vmem", "total", "taken") if k in mix))
+    if a.json:
+        import json
+        import bench
+        with open(a.json, "w") as f:
+            json.dump({"kernel_source_sha256": bench.kernel_source_hash(),
+                       "workload": "%s, %d B, dict %d, stream index %d (bench.py's recipe)" % (a.kind, a.size, a.dict, a.index),
+                       "how": "tools/emu/profile.py: the generated symbol loop executed instruction by instruction on the CPU "
+                              "(bit-exact output), every executed instruction counted by class",
+                       "per_output_byte": {k: round(mix.get(k, 0) / n, 4) for k in ("salu", "valu", "branch", "misc", "lds", "vmem", "total", "taken")},
+                       "executed_instructions": r["executed"], "compressed_bytes": len(comp) - 13}, f, indent=1)
+            f.write("\n")
     if a.regions:
         c, tk = emu.counts()
         reg = {}
