@@ -1,0 +1,178 @@
+//! `extern "C"` declarations of include/milzma.h, one for one (struct layouts, constants, every exported
+//! symbol).  tests/test_host_abi.py diffs the function names and the struct field lists against the header.
+#![allow(non_camel_case_types, dead_code)]
+
+use std::os::raw::{c_char, c_float, c_int, c_void};
+
+pub const MILZMA_ABI_VERSION: u32 = 1;
+
+// error kinds: error::Error variants (src/error.rs:8-17)
+pub const MILZMA_OK: c_int = 0;
+pub const MILZMA_IO_ERROR: c_int = 1;
+pub const MILZMA_HEADER_TOO_SHORT: c_int = 2;
+pub const MILZMA_LZMA_ERROR: c_int = 3;
+pub const MILZMA_XZ_ERROR: c_int = 4;
+pub const MILZMA_INFRA_ERROR: c_int = 5;
+
+pub const MILZMA_KIND_RAW_LZMA: u8 = 0;
+pub const MILZMA_KIND_LZMA2: u8 = 1;
+pub const MILZMA_SIZE_UNKNOWN: u64 = u64::MAX;
+pub const MILZMA_NO_LIMIT: u64 = u64::MAX;
+pub const MILZMA_MAX_UNIT_BYTES: u64 = 0xFFFF_FF00;
+
+// unpacked_size_mode: decompress::UnpackedSize (src/decode/options.rs:22-43)
+pub const MILZMA_READ_FROM_HEADER: i32 = 0;
+pub const MILZMA_READ_HEADER_BUT_USE_PROVIDED: i32 = 1;
+pub const MILZMA_USE_PROVIDED: i32 = 2;
+
+pub const MILZMA_ST_OK: u32 = 0;
+pub const MILZMA_ST_OUT_FULL: u32 = 32;
+
+/// One independent serial decode job (one wavefront).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct milzma_unit {
+    pub in_off: u64,
+    pub in_len: u64,
+    pub out_off: u64,
+    pub out_cap: u64,
+    pub unpacked_size: u64,
+    pub memlimit: u64,
+    pub dict_size: u32,
+    pub lc: u8,
+    pub lp: u8,
+    pub pb: u8,
+    pub kind: u8,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct milzma_result {
+    pub status: u32,
+    pub chunks: u32,
+    pub out_len: u64,
+    pub out_flushed: u64,
+    pub in_consumed: u64,
+    pub err_a: u64,
+    pub err_b: u64,
+}
+
+/// decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct milzma_options {
+    pub unpacked_size_mode: i32,
+    pub provided_is_some: i32,
+    pub provided: u64,
+    pub memlimit_is_some: i32,
+    pub reserved: i32,
+    pub memlimit: u64,
+}
+
+/// What a whole-file call did to the caller's reader and writer.
+#[repr(C)]
+pub struct milzma_output {
+    pub data: *mut u8,
+    pub len: usize,
+    pub in_consumed: usize,
+    pub kind: i32,
+    pub msg: [c_char; 388],
+}
+
+#[repr(C)]
+pub struct milzma_ctx {
+    _opaque: [u8; 0],
+}
+
+extern "C" {
+    pub fn milzma_abi_version() -> u32;
+    pub fn milzma_create(device: c_int, out_ctx: *mut *mut milzma_ctx) -> c_int;
+    pub fn milzma_destroy(ctx: *mut milzma_ctx);
+    pub fn milzma_last_error(ctx: *const milzma_ctx) -> *const c_char;
+
+    pub fn milzma_decode_units(
+        ctx: *mut milzma_ctx,
+        units: *const milzma_unit,
+        n: u32,
+        d_in: *const c_void,
+        d_out: *mut c_void,
+        results: *mut milzma_result,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn milzma_decode_units_host(
+        ctx: *mut milzma_ctx,
+        units: *const milzma_unit,
+        n: u32,
+        h_in: *const c_void,
+        in_bytes: usize,
+        h_out: *mut c_void,
+        out_bytes: usize,
+        results: *mut milzma_result,
+    ) -> c_int;
+    pub fn milzma_last_kernel_ms(ctx: *const milzma_ctx, launches: *mut u32) -> c_float;
+    pub fn milzma_crc_units(
+        ctx: *mut milzma_ctx,
+        units: *const milzma_unit,
+        n: u32,
+        d_out: *const c_void,
+        results: *const milzma_result,
+        crc32: *mut u32,
+        crc64: *mut u64,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn milzma_result_message(r: *const milzma_result, unit_kind: u32, msg: *mut c_char, cap: usize) -> c_int;
+
+    pub fn milzma_default_options(opt: *mut milzma_options);
+    pub fn milzma_free(p: *mut c_void);
+
+    pub fn milzma_lzma_decompress(
+        ctx: *mut milzma_ctx,
+        input: *const u8,
+        in_len: usize,
+        opt: *const milzma_options,
+        out: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_lzma2_decompress(ctx: *mut milzma_ctx, input: *const u8, in_len: usize, out: *mut milzma_output) -> c_int;
+    pub fn milzma_xz_decompress(ctx: *mut milzma_ctx, input: *const u8, in_len: usize, out: *mut milzma_output) -> c_int;
+    pub fn milzma_lzma_decompress_batch(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        opt: *const milzma_options,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_lzma2_decompress_batch(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_xz_decompress_batch(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
+
+    pub fn milzma_lzma_read_header(
+        input: *const u8,
+        in_len: usize,
+        opt: *const milzma_options,
+        unit: *mut milzma_unit,
+        header_len: *mut usize,
+        out: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_xz_plan(
+        input: *const u8,
+        in_len: usize,
+        units: *mut milzma_unit,
+        cap: u32,
+        n_units: *mut u32,
+        check_id: *mut u32,
+    ) -> c_int;
+    pub fn milzma_crc32(p: *const u8, n: usize) -> u32;
+    pub fn milzma_crc64(p: *const u8, n: usize) -> u64;
+}

@@ -160,3 +160,23 @@ def test_asm_loop_wait_states():
             if op.startswith("s_cbranch"):
                 pass  # the fall-through continues the run
     assert checked > 400
+
+
+def test_rust_shim_declares_the_header_abi():
+    """integration/rust/src/ffi.rs (uncompilable here: no Rust toolchain) must declare exactly the functions of
+    include/milzma.h, with the same number of parameters, and the same struct fields in the same order."""
+    hdr = open(os.path.join(ROOT, "include", "milzma.h")).read()
+    rs = open(os.path.join(ROOT, "integration", "rust", "src", "ffi.rs")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    c_funcs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"])
+               for m in re.finditer(r"\b(milzma_\w+)\s*\(([^;{]*?)\)\s*;", hdr_nc)}
+    rs_funcs = {m.group(1): len([a for a in m.group(2).split(",") if ":" in a])
+                for m in re.finditer(r"pub fn (milzma_\w+)\s*\((.*?)\)", rs, flags=re.S)}
+    assert c_funcs == rs_funcs, (set(c_funcs) ^ set(rs_funcs), {k: (c_funcs[k], rs_funcs.get(k)) for k in c_funcs if c_funcs[k] != rs_funcs.get(k)})
+    assert set(c_funcs) == set(M.EXPORTS)
+    for name in ("milzma_unit", "milzma_result", "milzma_options", "milzma_output"):
+        cm = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr_nc, flags=re.S)
+        c_fields = [f for decl in cm.group(1).split(";") for f in re.findall(r"\b\*?(\w+)(?:\[\d+\])?\s*(?:,|$)", decl.strip().split(None, 1)[1] if len(decl.strip().split(None, 1)) > 1 else "")]
+        rm = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S)
+        r_fields = re.findall(r"pub (\w+):", rm.group(1))
+        assert c_fields == r_fields, (name, c_fields, r_fields)
