@@ -55,6 +55,7 @@ struct milzma_ctx {
   uint32_t last_launches = 0;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
+  uint32_t lds_pad = 0;  // MILZMA_LDS_PAD: bytes of unused dynamic LDS per block of the fast kernel (occupancy experiments)
 };
 
 namespace {
@@ -152,6 +153,9 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   if (const char* k = getenv("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
   }
+  if (const char* k = getenv("MILZMA_LDS_PAD")) {
+    ctx->lds_pad = uint32_t(strtoul(k, nullptr, 0));
+  }
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
       !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
     delete ctx;
@@ -226,7 +230,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
-    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream)
+    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad)
                                        : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;

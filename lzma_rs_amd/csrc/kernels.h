@@ -26,7 +26,7 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 
 // The lane-resident-model kernel (pb <= 2, lc + lp <= 3; symbol loop in gfx950 asm): 8 KiB LDS, 16 waves per CU.
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                       milzma_result* d_results, hipStream_t stream);
+                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad = 0);
 
 // Partial CRCs (64 chunks per unit) of the units' decoded output; see crc_units.hip.h.
 struct CrcParts;

@@ -209,8 +209,20 @@ static int lzbuf_append_literal(lzbuf_t *b, uint8_t lit, err_t *e) {
   return 0;
 }
 
+/* Workload statistics (tuning aid, not reference behaviour): matches by log2(distance) bucket and their bytes, filled
+ * while orc_match_hist points somewhere (single-threaded use only). hist[2*k] = matches with 2^k <= dist < 2^(k+1),
+ * hist[2*k+1] = bytes they copied. */
+static uint64_t *orc_match_hist_ptr = NULL;
+void orc_set_match_hist(uint64_t *hist64) { orc_match_hist_ptr = hist64; }
+
 /* LzBuffer::append_lz, lzbuffer.rs:123-141 (accum), :272-297 (ring) */
 static int lzbuf_append_lz(lzbuf_t *b, uint64_t len, uint64_t dist, err_t *e) {
+  if (orc_match_hist_ptr && dist) {
+    int k = 63 - __builtin_clzll(dist);
+    if (k > 31) k = 31;
+    orc_match_hist_ptr[2 * k] += 1;
+    orc_match_hist_ptr[2 * k + 1] += len;
+  }
   uint64_t i;
   if (b->is_accum) {
     size_t offset;

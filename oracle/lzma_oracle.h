@@ -87,6 +87,10 @@ int orc_lzma_raw_decompress(const uint8_t *in, size_t in_len, uint32_t lc, uint3
 
 /* CRCs used by the XZ layer (crate `crc` 3.0: CRC_32_ISO_HDLC, CRC_64_XZ;
  * src/xz/crc.rs:1-4). */
+/* Tuning aid: while `hist64` (64 counters) is set, every LZ77 copy adds to [2*floor(log2(dist))] (matches) and
+ * [2*floor(log2(dist)) + 1] (bytes).  NULL switches it off.  Not thread-safe. */
+void orc_set_match_hist(uint64_t *hist64);
+
 uint32_t orc_crc32(const uint8_t *p, size_t n);
 uint64_t orc_crc64(const uint8_t *p, size_t n);
 
