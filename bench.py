@@ -47,6 +47,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 CUS, CLOCK_GHZ = 256, 2.4  # scalar issue: one instruction per cycle per CU
 
+PROPS = (3, 0, 2)  # lc, lp, pb of the generated .lzma streams (--props; the forked compression workers inherit it)
+
 CONFIGS = {
     "lzma64k": dict(idx=1, streams=4096, size=1 << 20, dict=1 << 16, distinct=512),
     "dict8m": dict(idx=2, streams=4096, size=1 << 20, dict=1 << 23, distinct=512),
@@ -90,6 +92,7 @@ def _compress_range(job):
     pool's pipes would serialise on the parent).  Returns per item (compressed length, [crc32 per unit])."""
     from lzma_rs_amd import workloads as W
     mode, kind, size, dict_size, lo, hi, path = job
+    lc, lp, pb = PROPS
     meta = []
     with open(path, "wb") as f:
         for i in range(lo, hi):
@@ -99,7 +102,7 @@ def _compress_range(job):
                 crcs = [zlib.crc32(plain[o:o + (1 << 20)]) for o in range(0, size, 1 << 20)]
             else:
                 plain = W.make_plain(kind, size, W.SEED0 ^ i)
-                comp = W.compress_alone(plain, dict_size=dict_size, known_size=True)
+                comp = W.compress_alone(plain, dict_size=dict_size, lc=lc, lp=lp, pb=pb, known_size=True)
                 crcs = [zlib.crc32(plain)]
             f.write(comp)
             meta.append((len(comp), crcs))
@@ -261,6 +264,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=-1,
                     help="distinct streams compressed per GPU (0 = all; fewer are tiled over the slots, each "
                          "slot still reads its own copy of the input and writes its own output slice)")
+    ap.add_argument("--props", default="3,0,2", help="lc,lp,pb of the generated .lzma streams (default: the BASELINE's 3,0,2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pcie", action="store_true",
@@ -279,6 +283,8 @@ def main():
     import lzma_rs_amd as M
     from lzma_rs_amd import distributed as D
 
+    global PROPS
+    PROPS = tuple(int(x) for x in args.props.split(","))
     cfg = CONFIGS[args.config]
     mode = "xz" if args.config == "xz" else "lzma"
     n = args.streams or cfg["streams"]
@@ -459,8 +465,8 @@ def main():
             "streams_per_s": round(n * world / step_s, 1),
             "bit_exact": bad_total == 0,
             "config": {
-                "workload": "configs[%d]: %s, lc3/lp0/pb2, dict %d, class %s, liblzma preset 6, known-size headers"
-                            % (cfg["idx"], what, dict_size, args.kind),
+                "workload": "configs[%d]: %s, lc%d/lp%d/pb%d, dict %d, class %s, liblzma preset 6, known-size headers"
+                            % ((cfg["idx"], what) + PROPS + (dict_size, args.kind)),
                 "streams_per_gpu": n, "units_per_gpu": n_units, "distinct_streams_per_gpu": distinct, "stream_bytes": size,
                 "dict_size": dict_size, "class": args.kind,
                 "compressed_bytes_per_gpu": comp_total, "parallelism": "streams sharded, %d per GPU" % n,

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 
 def batch_path(a):
-    return "/tmp/milzma_ab_%s_%d_%d_%d.pkl" % (a.kind, a.distinct, a.size, a.dict)
+    return "/tmp/milzma_ab_%s_%d_%d_%d_%s.pkl" % (a.kind, a.distinct, a.size, a.dict, a.props.replace(",", ""))
 
 
 def worker(a):
@@ -30,6 +30,7 @@ def worker(a):
     from lzma_rs_amd import workloads as W
     import bench
     path = batch_path(a)
+    bench.PROPS = tuple(int(x) for x in a.props.split(","))
     if os.path.exists(path):
         with open(path, "rb") as f:
             blob, unit_bytes, crcs = pickle.load(f)
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 20)
     ap.add_argument("--dict", type=int, default=1 << 16)
     ap.add_argument("--kind", default="text")
+    ap.add_argument("--props", default="3,0,2")
     ap.add_argument("--wavetime", action="store_true")
     ap.add_argument("--worker", action="store_true")
     ap.add_argument("libs", nargs="*")

@@ -9,7 +9,7 @@ namespace milzma {
 
 // Launch classes: which kernel, and for the generic one how much of the model lives in LDS.
 enum LitClass : int {
-  kFast = 0,      // decode_fast_asm_kernel: pb <= 2, lc+lp <= 3, model in VGPR lanes, 16 waves per CU
+  kFast = 0,      // decode_fast_asm_kernel: lc+lp <= 3 (any pb), model in VGPR lanes, 16 waves per CU
   kLitLds3 = 1,   // generic kernel, literal table for lc+lp <= 3 in LDS (15 984 B per wave: 10 waves per CU)
   kLitLds4 = 2,   // generic kernel, lc+lp <= 4 in LDS (28 272 B per wave: 5 waves per CU)
   kLitSpill = 3,  // generic kernel, literal table in HBM scratch (lc+lp up to 12), small tables in LDS
@@ -24,7 +24,7 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
                           const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, uint16_t* d_scratch,
                           hipStream_t stream);
 
-// The lane-resident-model kernel (pb <= 2, lc + lp <= 3; symbol loop in gfx950 asm): 8 KiB LDS, 16 waves per CU.
+// The lane-resident-model kernel (lc + lp <= 3; symbol loop in gfx950 asm): 8 KiB LDS, 16 waves per CU.
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                        milzma_result* d_results, hipStream_t stream, uint32_t lds_pad = 0);
 

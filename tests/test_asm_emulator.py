@@ -29,7 +29,7 @@ def _hdr(comp):
 
 @pytest.fixture(scope="module")
 def loops():
-    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False)}
+    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}
     yield m
     for a in m.values():
         a.close()
@@ -37,7 +37,7 @@ def loops():
 
 def _check(loops, comp, plain):
     lc, lp, pb, ds, us = _hdr(comp)
-    r = loops[lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
+    r = loops["pb4" if pb > 2 else lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
     ref = orc.lzma_decompress(comp)
     assert ref.out == plain
     assert r["status"] == "OK" and r["out"] == plain
@@ -52,11 +52,13 @@ def test_emulated_loop_bench_classes(loops, kind, known):
         _check(loops, W.compress_alone(plain, dict_size=65536, known_size=known), plain)
 
 
-@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (3, 0, 0)])
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (3, 0, 0), (3, 0, 4), (3, 0, 3),
+                                      (0, 0, 4), (1, 2, 3), (2, 1, 4), (0, 3, 4)])
 def test_emulated_loop_props_and_near_distances(loops, lc, lp, pb):
     """small dictionary: exercises the reverse-tree distance slots (4..13) and rep matches"""
     rnd = random.Random(lc * 100 + lp * 10 + pb)
-    plain = W.make_plain("text", 30000, seed=lc * 100 + lp * 10 + pb) + bytes(rnd.randrange(256) for _ in range(3000)) + b"abc" * 5000
+    plain = (W.make_plain("text", 30000, seed=lc * 100 + lp * 10 + pb) + bytes(rnd.randrange(256) for _ in range(3000)) + b"abc" * 5000 +
+             bytes(4000) + b"abcdefg" * 2000)
     filt = [{"id": lzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 12}]
     _check(loops, lzma.compress(plain, format=lzma.FORMAT_ALONE, filters=filt), plain)
 

@@ -180,13 +180,13 @@ def classify(text):
 class AsmLoop:
     """One wavefront running the generated loop on a raw LZMA stream."""
 
-    def __init__(self, lp0=True, gen_module=None):
+    def __init__(self, lp0=True, gen_module=None, pb4=False):
         import gen_fast_loop as G
         self.G = gen_module or G
         G = self.G
-        g = G.Gen(lp0)
+        g = G.Gen(lp0, pb4)
         g.build()
-        lines = g.main + g.cold + g.stubs
+        lines = g.main + g.cold + getattr(g, "cold2", []) + g.stubs
         g.cur = lines
         g.finish()
         # operand -> register: scalars from s0 (4-aligned quads for the two descriptors), vectors from v0

@@ -34,7 +34,7 @@ struct Ins {
   X(s_mov_b32) X(s_movk_i32) X(s_not_b32) X(s_brev_b32) X(s_add_u32) X(s_addc_u32) X(s_sub_u32) X(s_subb_u32)          \
   X(s_and_b32) X(s_or_b32) X(s_xor_b32) X(s_andn2_b32) X(s_lshl_b32) X(s_lshr_b32) X(s_ashr_i32) X(s_min_u32)          \
   X(s_max_u32) X(s_max_i32) X(s_min_i32) X(s_mul_i32) X(s_cselect_b32) X(s_cselect_b64) X(s_lshl2_add_u32)             \
-  X(s_lshl1_add_u32) X(s_lshl3_add_u32) X(s_and_b64) X(s_or_b64) X(s_mov_b64) X(s_lshl_b64) X(s_lshr_b64) X(s_bfe_u32)               \
+  X(s_lshl1_add_u32) X(s_lshl3_add_u32) X(s_lshl4_add_u32) X(s_and_b64) X(s_or_b64) X(s_mov_b64) X(s_lshl_b64) X(s_lshr_b64) X(s_bfe_u32)               \
   X(s_bfm_b32) X(s_flbit_i32_b32) X(s_ff1_i32_b32) X(s_ff1_i32_b64) X(s_bcnt1_i32_b32) X(s_cmp_eq_u32)                 \
   X(s_cmp_lg_u32) X(s_cmp_gt_u32) X(s_cmp_ge_u32) X(s_cmp_lt_u32) X(s_cmp_le_u32) X(s_cmp_lt_i32) X(s_cmp_gt_i32)      \
   X(s_cmpk_eq_u32) X(s_cmpk_lg_u32) X(s_cmpk_gt_u32) X(s_cmpk_ge_u32) X(s_cmpk_lt_u32) X(s_cmpk_le_u32)                \
@@ -225,8 +225,9 @@ long run(Emu& e, int start, long max_steps) {
       case OP_s_cselect_b64: ws64(e, I.a[0], e.scc ? rs64(e, I.a[1]) : rs64(e, I.a[2])); break;
       case OP_s_lshl1_add_u32:
       case OP_s_lshl2_add_u32:
-      case OP_s_lshl3_add_u32: {
-        int sh = I.op == OP_s_lshl1_add_u32 ? 1 : I.op == OP_s_lshl2_add_u32 ? 2 : 3;
+      case OP_s_lshl3_add_u32:
+      case OP_s_lshl4_add_u32: {
+        int sh = I.op == OP_s_lshl1_add_u32 ? 1 : I.op == OP_s_lshl2_add_u32 ? 2 : I.op == OP_s_lshl3_add_u32 ? 3 : 4;
         uint64_t r = (uint64_t(rs(e, I.a[1])) << sh) + rs(e, I.a[2]);
         ws(e, I.a[0], uint32_t(r));
         e.scc = (r >> 32) != 0;

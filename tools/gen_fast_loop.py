@@ -114,7 +114,10 @@ OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "
                "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc", "tbl_ready"]
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
-               "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val", "tbl_a", "tbl_b"]
+               "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val", "tbl_a", "tbl_b",
+               # pb 3 / 4 (PB4 variant): position states 4..15
+               "m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b",
+               "m_rlen_mid_b"]
 OPS_IN_S = ["out_lim", "safe_len", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
             "out_rsrc", "ldsbase"]
 OPS_IN_V = ["v_lane"]
@@ -134,9 +137,13 @@ def R(name):
 
 
 class Gen:
-    def __init__(self, lp0):
+    def __init__(self, lp0, pb4=False):
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
-        self.main, self.cold, self.stubs = [], [], []
+        # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
+        # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
+        # 8 + (pos_state & 7), heap-numbered down to lane 63), the four len choices move to lanes 48..51 of m_rep.
+        self.pb4 = pb4
+        self.main, self.cold, self.cold2, self.stubs = [], [], [], []  # (cold2: out-of-line code of code that is itself in `cold`)
         self.cur = self.main
         self.uid = 0
 
@@ -407,13 +414,34 @@ class Gen:
             e("s_and_b64 vcc, vcc, " + MPAIR)
         e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
 
-    def decide(self, T, ln, taken):
+    def decide(self, T, ln, taken, cmp_lane=None):
         """a decision that ends in a branch: falls through for a 0 bit, jumps to `taken` for a 1 bit.
         The code at `taken` must start with self.taken(T)."""
-        self.core(T, ln)
+        self.core(T, ln, cmp_lane=cmp_lane)
         self.e("s_cbranch_scc0 " + self.L(taken))
         self.post_known(T, True)
         self.norm()
+
+    def decide_by_reg(self, regs, ln, taken_pfx, join):
+        """decide() on probability `ln` (0..191) of a table that spans three registers; falls through at `join` for a 0
+        bit; a 1 bit arrives at taken_pfx + "2" with the update done (each register has its own taken stub)."""
+        e, L = self.e, self.L
+        e("s_cmp_lt_u32 {ln}, 64", ln=ln)
+        e("s_cbranch_scc0 " + L(taken_pfx + "_hi"))
+        self.decide(R(regs[0]), ln, taken_pfx + "_ta")   # (v_readlane takes the index's low 6 bits; the update mask compares
+        self.lab(join)                                    #  it with lane + 64 / lane + 128 for the other two registers)
+        with self.in_cold():
+            self.lab(taken_pfx + "_hi")
+            e("s_cmp_lt_u32 {ln}, 0x80", ln=ln)
+            e("s_cbranch_scc0 " + L(taken_pfx + "_hi2"))
+            self.decide(R(regs[1]), ln, taken_pfx + "_tb", cmp_lane=V["VLANE64"])
+            e("s_branch " + L(join))
+            self.lab(taken_pfx + "_hi2")
+            self.decide(R(regs[2]), ln, taken_pfx + "_tc", cmp_lane=V["VLANE128"])
+            e("s_branch " + L(join))
+            for tag, reg in zip("abc", regs):
+                self.lab(taken_pfx + "_t" + tag)
+                self.taken(R(reg), to=taken_pfx + "2")
 
     def taken(self, T, to=None):
         self.post_known(T, False)
@@ -483,7 +511,7 @@ class Gen:
         e, L = self.e, self.L
         e("s_getpc_b64 " + JBASE)
         self.lab("base")
-        vid = 1 if self.lp0 else 2                          # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
+        vid = 3 if self.pb4 else 1 if self.lp0 else 2       # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
         e("s_cmp_eq_u32 {tbl_ready}, %d" % vid)             #  unit may change lp, and with it the variant, between chunks)
         e("s_cbranch_scc1 " + L("tbl_done"))
         bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
@@ -550,32 +578,52 @@ class Gen:
         self.e("s_branch " + self.L("finish"))
 
     # ---- LenDecoder::decode ------------------------------------------------------------------------------
+    def len_tree3(self, reg, reg_b, tag):
+        """the 3-bit tree low[pos_state] / mid[pos_state]; leaves the inverted path in sym's low 3 bits.
+        4 position states: roots at lanes 4 + ps of `reg` (heap-numbered to lane 31).  16 (pb4): roots at lanes
+        8 + (ps & 7) of `reg` / `reg_b` by ps bit 3 (heap-numbered to lane 63)."""
+        e, L = self.e, self.L
+        if not self.pb4:
+            e("s_add_u32 {sym}, {ps}, 4")
+            self.tree_walk(R(reg), 3)
+            self.tree_update(R(reg), 5)
+            return
+        join = self.new("LT")
+        e("s_bitcmp1_b32 {ps}, 3")
+        e("s_cbranch_scc1 " + L(tag + "_psb"))
+        e("s_add_u32 {sym}, {ps}, 8")
+        self.tree_walk(R(reg), 3)
+        self.tree_update(R(reg), 6)
+        self.lab(join)
+        with Gen._Into(self, self.cold2):                 # (not the cold list: the callers may be emitting into it; not the
+            self.lab(tag + "_psb")                        #  stubs list: the walk's own normalisation stubs go there)
+            e("s_mov_b32 {sym}, {ps}")                    # 8 + (ps - 8)
+            self.tree_walk(R(reg_b), 3)
+            self.tree_update(R(reg_b), 6)
+            e("s_branch " + L(join))
+
     def len_decode(self, which, done):
-        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (the match length) in mlen; jumps to `done`.
-        low[ps] / mid[ps]: heap numbering from root 4 + ps (lanes 4..31 of m_*_low / m_*_mid)."""
+        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (the match length) in mlen; jumps to `done`."""
         p = "m_len" if which == 0 else "m_rlen"
         w = "l%d" % which
         choice, choice2 = str(48 + 2 * which), str(49 + 2 * which)
-        self.decide(R("m_ismatch"), choice, w + "_nlow")
-        self.e("s_add_u32 {sym}, {ps}, 4")
-        self.tree_walk(R(p + "_low"), 3)
-        self.tree_update(R(p + "_low"), 5)
+        CH = R("m_rep") if self.pb4 else R("m_ismatch")   # (pb4: is_match fills its registers; m_rep's lanes 48..51 are free)
+        self.decide(CH, choice, w + "_nlow")
+        self.len_tree3(p + "_low", p + "_low_b", w + "lo")
         self.e("s_and_b32 {t0}, {sym}, 7")                # length = 2 + path = 9 - inverted path
         self.e("s_sub_u32 {mlen}, 9, {t0}")
         self.lab(done)                                    # the common (short) lengths fall through
         with self.in_cold():
             self.lab(w + "_nlow")
-            self.taken(R("m_ismatch"))
-            self.decide(R("m_ismatch"), choice2, w + "_high")
-            self.e("s_add_u32 {sym}, {ps}, 4")
-            self.tree_walk(R(p + "_mid"), 3)
-            self.tree_update(R(p + "_mid"), 5)
+            self.taken(CH)
+            self.decide(CH, choice2, w + "_high")
+            self.len_tree3(p + "_mid", p + "_mid_b", w + "mi")
             self.e("s_and_b32 {t0}, {sym}, 7")            # length = 10 + path
             self.e("s_sub_u32 {mlen}, 17, {t0}")
             self.e("s_branch " + self.L(done))
             # high: tree of 8, nodes 1..63 in h0, 64..127 in h1, 128..191 in h2, 192..255 in h3
             self.lab(w + "_high")
-            self.taken(R("m_ismatch"))
+            self.taken(CH)
             self.tree_walk(R(p + "_h0"), 6, first_lane="1")
             self.tree_update(R(p + "_h0"), 6)
             self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
@@ -653,9 +701,16 @@ class Gen:
         e("s_cbranch_scc1 " + L("Otop_slow" + tag))
         lab("top2" + tag)
         e("s_and_b32 {ps}, {len}, {pbmask}")
-        e("s_lshl2_add_u32 {ln}, {state}, {ps}")
-        self.decide(R("m_ismatch"), R("ln"), "match")
+        if self.pb4:
+            e("s_lshl4_add_u32 {ln}, {state}, {ps}")
+            self.decide_by_reg(["m_ismatch", "m_ismatch_b", "m_ismatch_c"], R("ln"), "match" + tag, "lit" + tag)
+        else:
+            e("s_lshl2_add_u32 {ln}, {state}, {ps}")
+            self.decide(R("m_ismatch"), R("ln"), "match")
         with self.in_cold():
+            if self.pb4:
+                lab("match" + tag + "2")
+                e("s_branch " + L("match2"))
             lab("Otop_slow" + tag)
             if GUARD1:
                 # a literal decoded at len == out_lim < target: append_literal's error (lzbuffer.rs:206-217); its store fell
@@ -1025,8 +1080,11 @@ class Gen:
         # Section order: a new match falls through its distance tail into `copy`, and `copy` into the top after a match, so that
         # the only taken branches of a match are the computed jump into the direct bits and the loop's back edge.
         # ================= match (lzma.rs:480-523) =================
-        lab("match")
-        self.taken(R("m_ismatch"))
+        if self.pb4:
+            lab("match2")                                     # (the update of is_match was done by the register's own stub)
+        else:
+            lab("match")
+            self.taken(R("m_ismatch"))
         self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
         e("s_mov_b32 {rep3}, {rep2}")
         e("s_mov_b32 {rep2}, {rep1}")
@@ -1146,14 +1204,22 @@ class Gen:
         self.taken(R("m_rep"))
         e("s_add_u32 {ln}, {state}, 12")
         self.decide(R("m_rep"), R("ln"), "rep_123")           # is_rep_g0
-        e("s_lshl2_add_u32 {ln}, {state}, {ps}")
-        self.decide(R("m_rep0long"), R("ln"), "rep0_long")    # is_rep_0long
+        if self.pb4:
+            e("s_lshl4_add_u32 {ln}, {state}, {ps}")
+            self.decide_by_reg(["m_rep0long", "m_rep0long_b", "m_rep0long_c"], R("ln"), "rep0_long", "rep0_short")
+        else:
+            e("s_lshl2_add_u32 {ln}, {state}, {ps}")
+            self.decide(R("m_rep0long"), R("ln"), "rep0_long")    # is_rep_0long
         e("s_cmpk_lt_u32 {state}, 7")                        # short rep
         e("s_cselect_b32 {state}, 9, 11")
         e("s_mov_b32 {mlen}, 1")
         e("s_branch " + L("copy"))
-        lab("rep0_long")
-        self.taken(R("m_rep0long"), to="rep_len")
+        if self.pb4:
+            lab("rep0_long2")
+            e("s_branch " + L("rep_len"))
+        else:
+            lab("rep0_long")
+            self.taken(R("m_rep0long"), to="rep_len")
         lab("rep_123")
         self.taken(R("m_rep"))
         e("s_add_u32 {ln}, {state}, 24")
@@ -1298,17 +1364,17 @@ class Gen:
 
 def main():
     texts = {}
-    for name, lp0 in (("LP0", True), ("GEN", False)):
-        g = Gen(lp0)
+    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True)):
+        g = Gen(lp0, pb4)
         g.build()
-        lines = g.main + g.cold + g.stubs
+        lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
         g.finish()
         texts[name] = lines
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
-    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, MILZMA_FAST_LOOP_TEXT_GEN for any lp.")
+    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, MILZMA_FAST_LOOP_TEXT_GEN for any lp, MILZMA_FAST_LOOP_TEXT_PB4 for pb 3 / 4 (any lp).")
     out.append("// clang-format off")
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
