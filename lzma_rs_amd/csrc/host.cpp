@@ -212,6 +212,7 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   if (u.kind != MILZMA_KIND_RAW_LZMA) return ctx->use_fast ? kFast : kLitLds3;
   const uint32_t lclp = uint32_t(u.lc) + u.lp;
   if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return kFast;
+  if (ctx->use_fast && u.pb <= 4 && lclp == 4) return kFastLc4;
   if (lclp <= 3) return kLitLds3;
   if (lclp <= 4) return kLitLds4;
   return kLitSpill;
@@ -230,8 +231,9 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
-    const hipError_t le = cls == kFast ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad)
-                                       : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
+    const hipError_t le = cls == kFast || cls == kFastLc4
+                              ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4)
+                              : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
     if (!hip_ok(ctx, hipEventRecord(ctx->ev1, stream), "hipEventRecord")) return false;
@@ -303,10 +305,11 @@ static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, u
     return MILZMA_INFRA_ERROR;
 
   // Promotions: LZMA2 units whose chunks switched to properties outside their class's reach run
-  // again, from the start, in the next class up (fast -> generic/LDS3 -> generic/LDS4).
+  // again, from the start, in the next class up (fast -> fast/lc4, which covers every LZMA2-legal property set;
+  // with MILZMA_KERNEL=generic: generic/LDS3 -> generic/LDS4).
   for (int round = 0; round < 2; round++) {
     std::vector<uint32_t> again;
-    LitClass next = kLitLds3;
+    LitClass next = ctx->use_fast ? kFastLc4 : kLitLds3;
     for (uint32_t i = 0; i < n; i++) {
       if (round == 0 && results[i].status == MILZMA_ST_NEED_GENERIC) again.push_back(i);
       if (round == 1 && results[i].status == MILZMA_ST_NEED_LCLP && results[i].err_a <= 4) again.push_back(i);

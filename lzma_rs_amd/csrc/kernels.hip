@@ -36,10 +36,13 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 }
 
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad) {
+                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4) {
   if (n == 0) return hipSuccess;
   // lds_pad: unused dynamic LDS (MILZMA_LDS_PAD, tuning only): what an LDS-resident window of that size would do to occupancy
-  hipLaunchKernelGGL(decode_fast_asm_kernel, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results);
+  if (lc4)
+    hipLaunchKernelGGL(decode_fast_asm_kernel<16>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results);
+  else
+    hipLaunchKernelGGL(decode_fast_asm_kernel<8>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results);
   return hipGetLastError();
 }
 

@@ -29,7 +29,8 @@ def _hdr(comp):
 
 @pytest.fixture(scope="module")
 def loops():
-    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}
+    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "pb4": asmprog.AsmLoop(lp0=False, pb4=True),
+         "lc4": asmprog.AsmLoop(lp0=False, pb4=True, lc4=True)}
     yield m
     for a in m.values():
         a.close()
@@ -37,7 +38,7 @@ def loops():
 
 def _check(loops, comp, plain):
     lc, lp, pb, ds, us = _hdr(comp)
-    r = loops["pb4" if pb > 2 else lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
+    r = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
     ref = orc.lzma_decompress(comp)
     assert ref.out == plain
     assert r["status"] == "OK" and r["out"] == plain
@@ -53,7 +54,8 @@ def test_emulated_loop_bench_classes(loops, kind, known):
 
 
 @pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (3, 0, 0), (3, 0, 4), (3, 0, 3),
-                                      (0, 0, 4), (1, 2, 3), (2, 1, 4), (0, 3, 4)])
+                                      (0, 0, 4), (1, 2, 3), (2, 1, 4), (0, 3, 4), (4, 0, 4), (4, 0, 0), (0, 4, 2), (2, 2, 3),
+                                      (1, 3, 4), (3, 1, 2)])
 def test_emulated_loop_props_and_near_distances(loops, lc, lp, pb):
     """small dictionary: exercises the reverse-tree distance slots (4..13) and rep matches"""
     rnd = random.Random(lc * 100 + lp * 10 + pb)

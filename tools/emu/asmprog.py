@@ -180,11 +180,12 @@ def classify(text):
 class AsmLoop:
     """One wavefront running the generated loop on a raw LZMA stream."""
 
-    def __init__(self, lp0=True, gen_module=None, pb4=False):
+    def __init__(self, lp0=True, gen_module=None, pb4=False, lc4=False):
         import gen_fast_loop as G
         self.G = gen_module or G
         G = self.G
-        g = G.Gen(lp0, pb4)
+        g = G.Gen(lp0, pb4, lc4)
+        self.lit_regs, self.ps0 = G.LIT_REGS, int(G.PS0[1:])  # (this variant's fixed register numbering)
         g.build()
         lines = g.main + g.cold + getattr(g, "cold2", []) + g.stubs
         g.cur = lines
@@ -281,11 +282,11 @@ class AsmLoop:
         for name in G.OPS_INOUT_V:
             if name.startswith("m_") or name in ("u0", "u1", "u2", "u3"):
                 self.vset(self._vidx(name), 0x400)
-        for i in range(16):
+        for i in range(self.lit_regs):
             self.vset(64 + i, 0x04000400)
         for i in range(4):
-            self.vset(80 + i, 0x400)
-        lds = np.full(8 * 64 * 4, 0x04000400, dtype=np.uint32)
+            self.vset(self.ps0 + i, 0x400)
+        lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
         self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
         self.vset(self._vidx("v_lane"), lane)
         self.vset(self._vidx("pend_val"), 0)

@@ -94,18 +94,31 @@ MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 JBASE = "s[64:65]"  # address of Lbase (set once per entry): jump targets are table offsets from it
 RET = "s[92:93]"  # return address of the window refill subroutine
-V = dict(M0="v84", M1="v85", M2="v86", M3="v87", VT0="v88", VT1="v89", VT2="v90", VA="v91", VPS="v92",
-         vt="v93", VR="v94", VL16="v95", VOOB="v96", VKTOP="v97", vx="v98", VLANE64="v99", VLANE128="v100",
-         VLANE192="v101", vb="v102", VSH6="v103", VSH6M1="v104", VSH5="v105", VSH5M1="v106", VSH4="v107",
-         VSH4M1="v108", VLEVEL="v109", va="v110", vr="v112", VLANEM1="v113")
+_V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt=93, VR=94, VL16=95, VOOB=96, VKTOP=97, vx=98,
+           VLANE64=99, VLANE128=100, VLANE192=101, vb=102, VSH6=103, VSH6M1=104, VSH5=105, VSH5M1=106, VSH4=107, VSH4M1=108,
+           VLEVEL=109, va=110, vr=112, VLANEM1=113)
 if PAD_V:
-    V["vpad"] = "v111"
-MROW = "v[84:87]"
-LIT0, LIT1 = "v64", "v65"   # literal plain table: 16 dwords v64..v79 (fixed, indexed with s_set_gpr_idx)
-PS0 = "v80"                 # pos_slot trees for len_state 0..3: v80..v83
-PS0M2 = "v78"               # PS0 - 2: indexed with len_state + 2
+    _V0["vpad"] = 111
+V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
+LIT0, LIT1 = "v64", "v65"   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
+
+
+def set_layout(lc4):
+    """Fixed VGPR numbering of a variant: the plain literal table at v64.. (16 dwords for lc + lp <= 3, 32 for lc + lp = 4),
+    then the four pos_slot trees (PS0..), then the temporaries and per-lane constants."""
+    global V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS
+    off = 16 if lc4 else 0
+    LIT_REGS = 32 if lc4 else 16
+    V.clear()
+    V.update({k: "v%d" % (n + off) for k, n in _V0.items()})
+    MROW = "v[%d:%d]" % (84 + off, 87 + off)
+    PS0 = "v%d" % (80 + off)        # pos_slot trees for len_state 0..3
+    PS0M2 = "v%d" % (78 + off)      # PS0 - 2: indexed with len_state + 2
+    CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
+
+
+set_layout(False)
 CLOBBER_S = sorted(set(S.values()) | {"s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ the refill return address)
-CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
@@ -137,7 +150,9 @@ def R(name):
 
 
 class Gen:
-    def __init__(self, lp0, pb4=False):
+    def __init__(self, lp0, pb4=False, lc4=False):
+        set_layout(lc4)  # (lc4: lc + lp = 4 -- 16 literal rows; same code, other register numbers and 16 KiB of LDS rows)
+        self.lc4 = lc4
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
         # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
@@ -511,7 +526,7 @@ class Gen:
         e, L = self.e, self.L
         e("s_getpc_b64 " + JBASE)
         self.lab("base")
-        vid = 3 if self.pb4 else 1 if self.lp0 else 2       # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
+        vid = 4 if self.lc4 else 3 if self.pb4 else 1 if self.lp0 else 2  # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
         e("s_cmp_eq_u32 {tbl_ready}, %d" % vid)             #  unit may change lp, and with it the variant, between chunks)
         e("s_cbranch_scc1 " + L("tbl_done"))
         bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
@@ -1363,18 +1378,23 @@ class Gen:
 
 
 def main():
-    texts = {}
-    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True)):
-        g = Gen(lp0, pb4)
+    texts, clobbers, fixeds = {}, {}, {}
+    for name, lp0, pb4, lc4 in (("LP0", True, False, False), ("GEN", False, False, False), ("PB4", False, True, False),
+                                ("LC4", False, True, True)):
+        g = Gen(lp0, pb4, lc4)
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
         g.finish()
         texts[name] = lines
+        clobbers[name] = list(CLOBBER_V)
+        fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(LIT_REGS)] +
+                        ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)])
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
-    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, MILZMA_FAST_LOOP_TEXT_GEN for any lp, MILZMA_FAST_LOOP_TEXT_PB4 for pb 3 / 4 (any lp).")
+    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, _GEN for any lp, _PB4 for pb 3 / 4 (any lp); _LC4 for lc + lp = 4 (any pb; its own")
+    out.append("// register numbering: MILZMA_FAST_LOOP_OUTPUTS_LC4 / _CLOBBERS_LC4, used by the LC4 instantiation of the kernel).")
     out.append("// clang-format off")
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
@@ -1384,15 +1404,17 @@ def main():
         for l in lines:
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
-    fixed = ['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(16)] + ['"+{v%d}"(d.posslot[%d])' % (80 + i, i) for i in range(4)]
-    outs = [('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] + ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V] + fixed
+    assert clobbers["LP0"] == clobbers["GEN"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["GEN"] == fixeds["PB4"]
+    common = ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
+              ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V])
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
-    out.append("#define MILZMA_FAST_LOOP_OUTPUTS \\")
-    out.append("  " + ", \\\n  ".join(outs))
+    for sfx, name in (("", "LP0"), ("_LC4", "LC4")):
+        out.append("#define MILZMA_FAST_LOOP_OUTPUTS%s \\" % sfx)
+        out.append("  " + ", \\\n  ".join(common + fixeds[name]))
+        out.append("#define MILZMA_FAST_LOOP_CLOBBERS%s \\" % sfx)
+        out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + clobbers[name]) + ', "vcc", "scc", "memory"')
     out.append("#define MILZMA_FAST_LOOP_INPUTS \\")
     out.append("  " + ", \\\n  ".join(ins))
-    out.append("#define MILZMA_FAST_LOOP_CLOBBERS \\")
-    out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + CLOBBER_V) + ', "vcc", "scc", "memory"')
     out.append("#define MILZMA_FAST_LOOP_UNIFORM(d, rf) \\")
     out.append("  " + " \\\n  ".join("d.%s = rf(d.%s);" % (n, n) for n in OPS_INOUT_S))
     out.append("// clang-format on")
