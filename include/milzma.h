@@ -129,6 +129,16 @@ const char *milzma_last_error(const milzma_ctx *ctx);
 int milzma_decode_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_in,
                         void *d_out, milzma_result *results, void *hip_stream);
 
+/* The same call in two halves, for callers that overlap a batch's decode with other work (the copies of the
+ * next / previous batch on another stream, host-side parsing): _async enqueues the descriptor upload, the
+ * kernel launches and the result download on `hip_stream` and returns without waiting for the GPU (`units`
+ * may be freed right away; d_in / d_out must stay valid); _wait drains that stream, reruns the rare LZMA2 units
+ * that switched property class, and fills `results` (n entries).  One batch in flight per context; use
+ * one context per concurrent batch.  milzma_decode_units == _async followed by _wait. */
+int milzma_decode_units_async(milzma_ctx *ctx, const milzma_unit *units, uint32_t n,
+                              const void *d_in, void *d_out, void *hip_stream);
+int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
+
 /* Same, with host-resident input / output: the library stages both through device buffers it
  * owns (PCIe-inclusive path).  Every unit's slices are checked against in_bytes / out_bytes and
  * against each other (MILZMA_INFRA_ERROR, nothing decoded, if one lies outside or two outputs overlap). */

@@ -99,6 +99,15 @@ extern "C" {
         results: *mut milzma_result,
         hip_stream: *mut c_void,
     ) -> c_int;
+    pub fn milzma_decode_units_async(
+        ctx: *mut milzma_ctx,
+        units: *const milzma_unit,
+        n: u32,
+        d_in: *const c_void,
+        d_out: *mut c_void,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn milzma_decode_units_wait(ctx: *mut milzma_ctx, results: *mut milzma_result) -> c_int;
     pub fn milzma_decode_units_host(
         ctx: *mut milzma_ctx,
         units: *const milzma_unit,

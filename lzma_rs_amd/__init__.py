@@ -133,7 +133,7 @@ class _COutput(ctypes.Structure):
 
 EXPORTS = [
     "milzma_abi_version", "milzma_create", "milzma_destroy", "milzma_last_error",
-    "milzma_decode_units", "milzma_decode_units_host", "milzma_last_kernel_ms", "milzma_crc_units",
+    "milzma_decode_units", "milzma_decode_units_async", "milzma_decode_units_wait", "milzma_decode_units_host", "milzma_last_kernel_ms", "milzma_crc_units",
     "milzma_result_message", "milzma_default_options", "milzma_free",
     "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
     "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
@@ -167,6 +167,8 @@ def lib():
     L.milzma_last_error.restype = ctypes.c_char_p
     L.milzma_last_error.argtypes = [vp]
     L.milzma_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result), vp]
+    L.milzma_decode_units_async.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, vp]
+    L.milzma_decode_units_wait.argtypes = [vp, ctypes.POINTER(Result)]
     L.milzma_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz,
                                            ctypes.POINTER(Result)]
     L.milzma_crc_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, ctypes.POINTER(Result),
@@ -276,6 +278,22 @@ class Context:
                                       results, ctypes.c_void_p(stream))
         if r != OK:
             raise InfraError("milzma_decode_units: " + self.last_error())
+        launches = ctypes.c_uint32()
+        ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
+        return results, ms, launches.value
+
+    def decode_units_async(self, units, d_in, d_out, stream=0):
+        """Enqueue only (milzma_decode_units_async); finish with decode_units_wait(len(units))."""
+        r = lib().milzma_decode_units_async(self._h, units, len(units), ctypes.c_void_p(d_in), ctypes.c_void_p(d_out),
+                                            ctypes.c_void_p(stream))
+        if r != OK:
+            raise InfraError("milzma_decode_units_async: " + self.last_error())
+
+    def decode_units_wait(self, n):
+        """Returns (ctypes array of Result, kernel_ms, launches) of the batch in flight."""
+        results = (Result * n)()
+        if lib().milzma_decode_units_wait(self._h, results) != OK:
+            raise InfraError("milzma_decode_units_wait: " + self.last_error())
         launches = ctypes.c_uint32()
         ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
         return results, ms, launches.value

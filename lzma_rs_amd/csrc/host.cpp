@@ -51,6 +51,16 @@ struct milzma_ctx {
   PinBuf pin_in, pin_out, pin_small;
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // milzma_decode_units_async: what is in flight until milzma_decode_units_wait
+  std::vector<hipEvent_t> ev_pool;      // pairs (start, stop), one per kernel launch of the batch in flight
+  uint32_t ev_used = 0;
+  bool pending = false;
+  uint32_t pend_n = 0;
+  hipStream_t pend_stream = nullptr;
+  const uint8_t* pend_in = nullptr;
+  uint8_t* pend_out = nullptr;
+  std::vector<milzma_unit> pend_units;  // (the caller's array need not outlive the call)
+  PinBuf pin_results;
   float last_ms = 0.f;
   uint32_t last_launches = 0;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
@@ -178,6 +188,8 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   pin_release(ctx->pin_in);
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  pin_release(ctx->pin_results);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
@@ -230,45 +242,74 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   if (cls == kLitSpill && !dev_reserve(ctx, ctx->scratch, kSpillBytesPerBlock * std::min(n, kSpillBatch))) return false;
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
-    if (!hip_ok(ctx, hipEventRecord(ctx->ev0, stream), "hipEventRecord")) return false;
+    while (ctx->ev_pool.size() < size_t(ctx->ev_used) * 2 + 2) {
+      hipEvent_t e = nullptr;
+      if (!hip_ok(ctx, hipEventCreate(&e), "hipEventCreate")) return false;
+      ctx->ev_pool.push_back(e);
+    }
+    hipEvent_t e0 = ctx->ev_pool[size_t(ctx->ev_used) * 2], e1 = ctx->ev_pool[size_t(ctx->ev_used) * 2 + 1];
+    if (!hip_ok(ctx, hipEventRecord(e0, stream), "hipEventRecord")) return false;
     const hipError_t le = cls == kFast || cls == kFastLc4
                               ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4)
                               : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
-    if (!hip_ok(ctx, hipEventRecord(ctx->ev1, stream), "hipEventRecord")) return false;
-    if (!hip_ok(ctx, hipEventSynchronize(ctx->ev1), "hipEventSynchronize")) return false;
+    if (!hip_ok(ctx, hipEventRecord(e1, stream), "hipEventRecord")) return false;
+    ctx->ev_used++;  // (timed in collect_kernel_ms once the stream has drained: nothing here waits for the GPU)
+  }
+  return true;
+}
+
+// kernel time of the launches enqueued since ev_used was last reset; the stream must have been synchronised
+bool collect_kernel_ms(milzma_ctx* ctx) {
+  for (uint32_t k = 0; k < ctx->ev_used; k++) {
     float ms = 0.f;
-    if (!hip_ok(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime")) return false;
+    if (!hip_ok(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[size_t(k) * 2], ctx->ev_pool[size_t(k) * 2 + 1]), "hipEventElapsedTime"))
+      return false;
     ctx->last_ms += ms;
     ctx->last_launches++;
   }
+  ctx->ev_used = 0;
   return true;
 }
 
 }  // namespace
 
-static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
-                                   void* d_out, milzma_result* results, void* hip_stream) {
+// Enqueue: descriptor upload, one launch per class, result download into a page-locked buffer -- all on `stream`,
+// nothing waits for the GPU.
+static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
+                                          void* d_out, void* hip_stream) {
   if (!ctx) return MILZMA_INFRA_ERROR;
-  ctx->last_ms = 0.f;
-  ctx->last_launches = 0;
-  if (n == 0) return MILZMA_OK;
-  if (!units || !results) {
-    ctx->err = "null units/results";
+  if (ctx->pending) {
+    ctx->err = "a batch is already in flight on this context: call milzma_decode_units_wait first";
     return MILZMA_INFRA_ERROR;
   }
-  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return MILZMA_INFRA_ERROR;
+  ctx->last_ms = 0.f;
+  ctx->last_launches = 0;
+  ctx->ev_used = 0;
+  ctx->pend_n = n;
+  ctx->pending = true;
+  if (n == 0) return MILZMA_OK;
+  if (!units) {
+    ctx->pending = false;
+    ctx->err = "null units";
+    return MILZMA_INFRA_ERROR;
+  }
+  const auto fail = [&]() {
+    ctx->pending = false;
+    return MILZMA_INFRA_ERROR;
+  };
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail();
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  ctx->pend_stream = stream;
+  ctx->pend_in = static_cast<const uint8_t*>(d_in);
+  ctx->pend_out = static_cast<uint8_t*>(d_out);
   // LzmaParams::read_header raises a dictionary below 4 KiB to 4 KiB (lzma.rs:118-120); a RAW unit built by hand gets
   // the same floor (the kernels divide by dict_size).
-  std::vector<milzma_unit> fixed;
-  for (uint32_t i = 0; i < n; i++)
-    if (units[i].kind == MILZMA_KIND_RAW_LZMA && units[i].dict_size < 0x1000u) {
-      if (fixed.empty()) fixed.assign(units, units + n);
-      fixed[i].dict_size = 0x1000u;
-    }
-  if (!fixed.empty()) units = fixed.data();
+  ctx->pend_units.assign(units, units + n);
+  for (milzma_unit& u : ctx->pend_units)
+    if (u.kind == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
+  units = ctx->pend_units.data();
 
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
@@ -286,23 +327,46 @@ static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, u
 
   if (!dev_reserve(ctx, ctx->units, size_t(n) * sizeof(milzma_unit)) ||
       !dev_reserve(ctx, ctx->order, size_t(n) * 2 * sizeof(uint32_t)) ||
-      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)))
-    return MILZMA_INFRA_ERROR;
+      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)) ||
+      !pin_reserve(ctx, ctx->pin_results, size_t(n) * (sizeof(milzma_result) + sizeof(uint32_t))))
+    return fail();
+  // (the order array is staged in page-locked memory behind the results so that its upload is asynchronous too)
+  uint32_t* h_order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->pin_results.p) + size_t(n) * sizeof(milzma_result));
+  memcpy(h_order, flat.data(), size_t(n) * sizeof(uint32_t));
   if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
               "H2D units") ||
-      !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, flat.data(), size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, stream),
+      !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h_order, size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, stream),
               "H2D order"))
-    return MILZMA_INFRA_ERROR;
+    return fail();
 
   for (int c = 0; c < kNumLitClasses; c++)
-    if (!launch_class(ctx, LitClass(c), order[c], base[c], static_cast<const uint8_t*>(d_in),
-                      static_cast<uint8_t*>(d_out), stream))
-      return MILZMA_INFRA_ERROR;
+    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream)) return fail();
 
-  if (!hip_ok(ctx, hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
-              "D2H results") ||
-      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+  if (!hip_ok(ctx, hipMemcpyAsync(ctx->pin_results.p, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
+              "D2H results"))
+    return fail();
+  return MILZMA_OK;
+}
+
+// Wait: drain the stream, time the launches, rerun promoted LZMA2 units, hand the results over.
+static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (!ctx->pending) {
+    ctx->err = "no batch in flight on this context";
     return MILZMA_INFRA_ERROR;
+  }
+  ctx->pending = false;
+  const uint32_t n = ctx->pend_n;
+  if (n == 0) return MILZMA_OK;
+  if (!results) {
+    ctx->err = "null results";
+    return MILZMA_INFRA_ERROR;
+  }
+  hipStream_t stream = ctx->pend_stream;
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") ||
+      !collect_kernel_ms(ctx))
+    return MILZMA_INFRA_ERROR;
+  memcpy(results, ctx->pin_results.p, size_t(n) * sizeof(milzma_result));
 
   // Promotions: LZMA2 units whose chunks switched to properties outside their class's reach run
   // again, from the start, in the next class up (fast -> fast/lc4, which covers every LZMA2-legal property set;
@@ -319,17 +383,28 @@ static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, u
     if (!hip_ok(ctx,
                 hipMemcpyAsync(static_cast<uint32_t*>(ctx->order.p) + n, again.data(), again.size() * sizeof(uint32_t),
                                hipMemcpyHostToDevice, stream),
-                "H2D order"))
+                "H2D order") ||
+        !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))  // (`again` is pageable and about to go away)
       return MILZMA_INFRA_ERROR;
-    if (!launch_class(ctx, next, again, n, static_cast<const uint8_t*>(d_in), static_cast<uint8_t*>(d_out), stream))
-      return MILZMA_INFRA_ERROR;
+    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream)) return MILZMA_INFRA_ERROR;
     if (!hip_ok(ctx,
                 hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
                 "D2H results") ||
-        !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+        !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") || !collect_kernel_ms(ctx))
       return MILZMA_INFRA_ERROR;
   }
   return MILZMA_OK;
+}
+
+static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
+                                   void* d_out, milzma_result* results, void* hip_stream) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (n && !results) {
+    ctx->err = "null units/results";
+    return MILZMA_INFRA_ERROR;
+  }
+  const int r = milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream);
+  return r != MILZMA_OK ? r : milzma_decode_units_wait_impl(ctx, results);
 }
 
 static int milzma_decode_units_host_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
@@ -1463,6 +1538,7 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
   try {
     return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
+    if (ctx) ctx->pending = false;
     if (ctx) ctx->err = std::string("host exception: ") + e.what();
     return MILZMA_INFRA_ERROR;
   }
@@ -1558,6 +1634,28 @@ extern "C" int milzma_xz_plan(const uint8_t* in, size_t in_len, milzma_unit* uni
     }
     return MILZMA_OK;
   } catch (const std::exception&) {
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_decode_units_async(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in, void* d_out,
+                                         void* hip_stream) {
+  try {
+    return milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream);
+  } catch (const std::exception& e) {
+    if (ctx) {
+      ctx->pending = false;
+      ctx->err = std::string("host exception: ") + e.what();
+    }
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results) {
+  try {
+    return milzma_decode_units_wait_impl(ctx, results);
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
     return MILZMA_INFRA_ERROR;
   }
 }

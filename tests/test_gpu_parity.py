@@ -576,3 +576,65 @@ def test_hostile_declared_sizes(ctx):
     outs = ctx.lzma_batch(good[:3] + [lie] + good[3:])
     for d, c in zip(outs, good[:3] + [lie] + good[3:]):   # the liar does not take its neighbours down
         same(d, orc.lzma_decompress(c))
+
+
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 4), (3, 0, 3), (4, 0, 4), (2, 2, 3), (0, 4, 0), (1, 2, 4)])
+def test_property_classes_at_size(ctx, lc, lp, pb):
+    """text streams of 256 KiB in the property classes served by the PB4 variant (16 position states) and the LC4
+    instantiation (lc + lp = 4) of the asm kernel, device-resident, against the oracle (rangecoder.rs:153-270 LenDecoder
+    per pos_state; lzma.rs:526-561 literal rows)."""
+    import torch
+    n, size = 6, 1 << 18
+    plains = [W.make_plain("text", size, seed=1000 + i + lc * 7 + lp * 5 + pb) for i in range(n)]
+    comps = [W.compress_alone(p, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=bool(i & 1)) for i, p in enumerate(plains)]
+    units = (M.Unit * n)()
+    in_off, blobs = 0, []
+    for i, c in enumerate(comps):
+        u, hl = M.lzma_read_header(c)
+        payload = c[hl:]
+        u.in_off, u.in_len = in_off, len(payload)
+        u.out_off, u.out_cap = i * size, size
+        units[i] = u
+        blobs.append(payload + bytes((-len(payload)) % 256))
+        in_off += len(blobs[-1])
+    d_in = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(n * size, dtype=torch.uint8, device="cuda")
+    res, _, launches = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), 0)
+    assert launches == 1
+    host = d_out.cpu().numpy().tobytes()
+    for i in range(n):
+        ref = orc.lzma_decompress(comps[i])
+        assert ref.ok and ref.out == plains[i]
+        assert res[i].status == M.ST_OK and res[i].out_len == size and host[i * size:(i + 1) * size] == ref.out
+        assert res[i].in_consumed + 13 == ref.in_consumed
+
+
+def test_decode_units_async_overlaps_and_matches_sync(ctx):
+    """milzma_decode_units_async / _wait: returns before the GPU is done, the caller's unit array may go away, one batch
+    per context, same results as the synchronous call"""
+    import torch
+    comps, plains = W.make_lzma_batch(8, size=1 << 18, kind="text", dict_size=65536, known_size=True, keep_plain=True)
+    n = len(comps)
+    units = (M.Unit * n)()
+    in_off, blobs = 0, []
+    for i, c in enumerate(comps):
+        u, hl = M.lzma_read_header(c)
+        payload = c[hl:]
+        u.in_off, u.in_len, u.out_off, u.out_cap = in_off, len(payload), i << 18, 1 << 18
+        units[i] = u
+        blobs.append(payload + bytes((-len(payload)) % 256))
+        in_off += len(blobs[-1])
+    d_in = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(n << 18, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    ctx.decode_units_async(units, d_in.data_ptr(), d_out.data_ptr(), st.cuda_stream)
+    with pytest.raises(M.InfraError):
+        ctx.decode_units_async(units, d_in.data_ptr(), d_out.data_ptr(), st.cuda_stream)  # one batch per context
+    del units  # (the library keeps its own copy of the descriptors)
+    res, ms, launches = ctx.decode_units_wait(n)
+    assert launches == 1 and ms > 0
+    host = d_out.cpu().numpy().tobytes()
+    for i in range(n):
+        assert res[i].status == M.ST_OK and host[i << 18:(i + 1) << 18] == plains[i]
+    with pytest.raises(M.InfraError):
+        ctx.decode_units_wait(n)  # nothing in flight

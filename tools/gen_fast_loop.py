@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Generates lzma_rs_amd/csrc/fast_loop_asm.inc: the LZMA symbol loop of the fast kernel as ONE gfx950
-inline-asm statement (text + operand lists), so that nothing in the hot loop is left to hipcc's
-register allocator / block placement (rocprof on the C++ loop: 45 % of issued instructions were
-phi copies and other compiler glue).
+inline-asm statement per variant (text + operand lists), so that nothing in the hot loop is left to hipcc's
+register allocator / block placement (rocprof on a C++ loop: 45 % of issued instructions were phi copies and
+other compiler glue).  Variants: LP0 (lp == 0, pb <= 2), GEN (any lp, pb <= 2), PB4 (pb 3 / 4), LC4 (lc + lp = 4,
+own register numbering, used by the <16> instantiation of the kernel).
 
 What the loop does is DecoderState::process_mode(Finish) (src/decode/lzma.rs:435-524) with
 decode_literal (526-561), decode_distance (563-592), LenDecoder::decode (rangecoder.rs:256-269),
@@ -11,31 +12,44 @@ LzCircularBuffer::append_lz (lzbuffer.rs:255-281).  Everything rare leaves the l
 and is finished by the C++ around it (decode_fast_asm.hip.h): errors, long or clipped matches, the
 end-of-stream marker, the output limit.
 
+Every change here is checked on the CPU first: tools/emu executes the generated text instruction by
+instruction (tests/test_asm_emulator.py) and counts what runs (tools/emu/profile.py).
+
 Conventions inside the loop
-  * range, code and every piece of LZMA state are SGPRs; the probability model is lane-resident
-    (one probability per lane of a VGPR, see decode_fast_asm.hip.h for the layout).
-  * A decision: every lane computes the bound of its own probability, (range >> 11) * p (v_lshrrev,
-    v_mul_u32_u24), v_readlane picks the node's; s_sub of code - bound sets SCC = (code < bound) = "bit is 0";
-    two s_cselect pick range / code.  No EXEC manipulation anywhere.
-  * The scalar pipe (one instruction per cycle per CU, shared by the CU's 16 waves) is the binding unit, so
-    whatever can be done on the vector ALU or once instead of per decision is:
+  * range and code are the aligned SGPR pair s[66:67]; every other piece of LZMA state is an SGPR too; the
+    probability model is lane-resident (one probability per lane of a VGPR, see decode_fast_asm.hip.h).
+  * A decision, form A (single decisions: is_match, is_rep ..., literal levels 6-7, matched literals): every
+    lane computes the bound of its own probability, (range >> 11) * p (v_lshrrev, v_mul_u32_u24), v_readlane
+    picks the node's; s_sub of code - bound sets SCC = (code < bound) = "bit is 0"; two s_cselect pick
+    range / code.  Form B (walks of a tree whose update is deferred): the vector ALU also delivers
+    range - bound, two v_readlane fill scalar pairs and ONE s_cselect_b64 picks (bound, code) or
+    (range - bound, code - bound): 3 scalar + 5 vector instructions, no wait state.  No EXEC manipulation anywhere.
+  * What the hardware charges (measured at full occupancy, profiles/r02_*): a scalar instruction costs 2.5x a
+    vector one; a DEPENDENT vector instruction on the decision chain about as much as two scalar ones; a taken
+    branch next to nothing.  Hence:
       - the probabilities of a walked tree are updated once per walk (tree_update): the final symbol names the
         visited node of every level and the bit decided there, so every lane can tell from its own index
         whether it was visited; single decisions update their lane under a v_cmp_eq(lane) / v_cndmask mask,
         on the side of the branch that knows the bit where there is one;
-      - the "range < 2^24" test is a v_cmp + s_cbranch_vccnz;
-      - rare conditions share a guard: one compare at the top of a symbol for "size reached" / "reader may be at
-        EOF", one per match for "near the output limit".
+      - rare conditions share a guard: one compare at the top of a symbol (gtop: size reached / reader may be at
+        EOF / within 273 bytes of the output limit), one per match (gdist: distance beyond min(len, dict_size), end
+        marker, length >= 64, near the output limit);
+      - the pos_slot walk's final symbol indexes two per-lane tables: the distance base and the ADDRESS of the code
+        that continues this slot (tables_prologue); one s_setpc_b64 enters the chain of 26 direct-bit blocks so that
+        exactly the needed number run.
+  * The SIMD's arbiter serves its waves oldest first, which starves the youngest of four equally busy waves (and the
+    kernel ends with the slowest): every window refill sets s_setprio (((s_memtime >> 21) + wave slot) & 3), so the
+    four waves of a SIMD take turns at every priority and finish within 2 % of each other.
   * Symbols are accumulated with s_addc, i.e. with INVERTED bits (SCC = bit is 0).  Tree nodes are
     therefore stored at the lane of the inverted path, which is a permutation inside each tree level
     and costs nothing (all probabilities start equal); decoded values are un-inverted once per symbol.
   * Trees whose first node is not lane 1 use heap numbering from another root (root r: children 2r,
     2r+1), so that the running symbol IS the lane and no per-bit address add is needed.
-  * Normalisation (1 in ~8 decisions) is an out-of-line stub per site; taken branches only stall the
-    wave that takes them, while every extra ALU instruction costs issue bandwidth all 16 waves of
-    the CU compete for -- so rare work is always moved behind a branch.
+  * Normalisation (one per input byte) is an out-of-line stub per site behind s_cmp_lt_u32 + s_cbranch_scc1.
   * Input: a 64-byte window, one byte per lane (winb), the next one prefetched (winb_next); `off` is
     the lane of the next byte, `lim` the value of `off` at which the decoder's reader is at EOF.
+  * Emission lists: main (hot fall-through path), cold (out of line), cold2 (out-of-line code of code that is itself
+    in cold), stubs (normalisation / mismatch stubs); concatenated in that order.
   * gfx940-family wait states hipcc would insert but inline asm must provide itself: one between a VALU write
     of a VGPR and a v_readlane of it (measured: without it every stream decodes wrongly), two between a VALU
     write of VCC and a VALU read of it (tests/test_host_abi.py lints the generated text for both).
@@ -44,25 +58,10 @@ import os
 import re
 
 PEND_UNKNOWN = 0x100  # pend_n value meaning "no pending match, but prev / mb are not at hand"
-K_ON_VALU = os.environ.get("MILZMA_GEN_K_ON_VALU", "0") == "1"  # update constant of tree decisions: v_and/v_mad or s_cselect
 LOAD_MOD = os.environ.get("MILZMA_GEN_LOAD_MOD", "")    # cache-policy bits of the match-source load (experiments)
 STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / match stores
-WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"
-WAITPROF2 = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "2"  # tuning: isolated round trips of a literal's byte store / a match's load  # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
-INTERLEAVE = os.environ.get("MILZMA_GEN_INTERLEAVE", "0") == "1"  # alternate scalar and vector instructions inside a tree decision (measured: -1 %)
-DEFER = os.environ.get("MILZMA_GEN_DEFER", "1") == "1"  # update a tree's probabilities once per tree walk, from the final symbol
-JUMP = os.environ.get("MILZMA_GEN_JUMP", "1") == "1"
-# pos_slot -> (distance base, jump target) through two per-lane constant tables instead of ~15 scalar instructions and
-# three branches per match
-TABLES = os.environ.get("MILZMA_GEN_TABLES", "1") == "1"
-# GUARD1: one guard per match (rep0 >= gdist) and one per symbol top (len >= gtop): gdist is 0 while a match needs a closer
-# look (length >= 64, within 273 bytes of the output limit), gtop <= safe_len + 1, so the literal needs no limit test
-GUARD1 = os.environ.get("MILZMA_GEN_GUARD1", "1") == "1"
-NORM_INLINE = os.environ.get("MILZMA_GEN_NORM_INLINE", "0") == "1"  # normalisation inline, skipped by a short forward branch  # enter the chain of direct bits with a computed jump instead of looping
-PREFETCH = os.environ.get("MILZMA_GEN_PREFETCH", "0") == "1"  # scalar loads that pull a match's source lines into L2 early (measured: the
-# matched-literal wait drops from 2.5 to 1.0 us, the batch time does not: the ALU pipes, not the wait, bound a full CU)
-BOUND_ON_VALU = os.environ.get("MILZMA_GEN_BOUND_ON_VALU", "1") == "1"  # (range >> 11) * p for all lanes, then v_readlane
-assert not (WAITPROF and PREFETCH), "the wait profile borrows the prefetch registers"
+WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"   # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
+WAITPROF2 = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "2"  # tuning: isolated round trips of a literal's byte store / a match's load
 # sensitivity probes (tuning only): k dead scalar / vector / never-taken-branch instructions per adaptive decision
 PAD_S = int(os.environ.get("MILZMA_GEN_PAD_S", "0"))
 PAD_V = int(os.environ.get("MILZMA_GEN_PAD_V", "0"))
@@ -89,7 +88,8 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pad="s69", prioph="s68", jb_lo="s64", jb_hi="s65", pf0="s94", pf1="s95", pf2="s96", pl0="s97", gtop="s70", gdist="s71")
+         c2017="s90", c2048="s91", pad="s69", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 JBASE = "s[64:65]"  # address of Lbase (set once per entry): jump targets are table offsets from it
@@ -199,25 +199,6 @@ class Gen:
         """RangeDecoder::normalize (rangecoder.rs:59-69) as a check + out-of-line stub.
         `to`: label to continue at (default: fall through)."""
         k = self.new("N")
-        if NORM_INLINE:
-            skip = self.new("S")
-            self.e("s_cmp_lt_u32 {range}, 0x1000000")
-            self.e("s_cbranch_scc0 " + self.L(to if to is not None else skip))
-            self.e("s_cmp_eq_u32 {off}, {lim}")
-            self.e("s_cbranch_scc1 " + self.L("Xeof"))
-            self.e("v_readlane_b32 {n1}, {winb}, {off}")
-            self.e("s_lshl_b32 {range}, {range}, 8")
-            self.e("s_lshl_b32 {code}, {code}, 8")
-            self.e("s_or_b32 {code}, {code}, {n1}")
-            self.e("s_add_u32 {off}, {off}, 1")
-            self.e("s_bitcmp1_b32 {off}, 6")
-            self.e("s_cbranch_scc0 " + self.L(to if to is not None else skip))
-            self.e("s_call_b64 " + RET + ", " + self.L("refill"))
-            if to is not None:
-                self.e("s_branch " + self.L(to))
-            else:
-                self.lab(skip)
-            return
         if kind in NORM_S:
             self.e("s_cmp_lt_u32 {range}, 0x1000000")
             self.e("s_cbranch_scc1 " + self.L(k))
@@ -271,27 +252,15 @@ class Gen:
             self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
             return
-        if BOUND_ON_VALU:
-            # every lane computes the bound of its own probability; the one that is needed is read out
-            self.e("v_lshrrev_b32 {vt}, 11, {range}")
-            if half == 0:
-                self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
-            elif half == 1:
-                self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
-            self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
-            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))  # (also keeps the
-            self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)  # v_readlane one instruction away from vb's producer)
-        else:
-            self.e("v_readlane_b32 {sp}, {T}, {ln}", T=T, ln=ln)
-            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
-            if half == 0:
-                self.e("s_and_b32 {sp}, {sp}, 0xffff")
-                self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
-            elif half == 1:
-                self.e("s_lshr_b32 {sp}, {sp}, 16")
-                self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
-            self.e("s_lshr_b32 {sb}, {range}, 11")
-            self.e("s_mul_i32 {sb}, {sb}, {sp}")
+        # form A: every lane computes the bound of its own probability; the one that is needed is read out
+        self.e("v_lshrrev_b32 {vt}, 11, {range}")
+        if half == 0:
+            self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
+        elif half == 1:
+            self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
+        self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
+        self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))  # (also keeps the
+        self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)  # v_readlane one instruction away from vb's producer)
         self.e("s_sub_u32 {sr1}, {range}, {sb}")
         self.e("s_sub_u32 {sc1}, {code}, {sb}")          # SCC = code < bound  <=>  bit == 0
         self.e("s_cselect_b32 {range}, {sb}, {sr1}")
@@ -318,52 +287,22 @@ class Gen:
 
     def pre_sym(self):
         """scalar part of the update of a tree decision; call while SCC = (bit == 0)"""
-        if not K_ON_VALU:
-            self.e("s_cselect_b32 {sk}, {c2048}, 31")
+        self.e("s_cselect_b32 {sk}, {c2048}, 31")
 
     def post_sym(self, T, half=None):
         """probability update of a tree decision (the symbol's new low bit is 1 if the bit was 0)"""
         if half is None:
-            if K_ON_VALU:
-                self.e("v_and_b32 {vt}, 1, {sym}")
-                self.e("v_mad_u32_u24 {vt}, {vt}, {c2017}, 31")       # K = 31 + 2017 * low bit
-                self.e("v_mad_u32_u24 {vt}, {T}, 31, {vt}", T=T)
-            else:
-                self.e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
+            self.e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
             self.e("v_lshrrev_b32 {vt}, 5, {vt}")
             self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
             return
-        if K_ON_VALU:
-            self.e("v_sub_u32 {vx}, 31, {vx}")
-            self.e("v_and_b32 {vt}, 1, {sym}")
-            self.e("v_mad_u32_u24 {vt}, {vt}, {c2017}, {vx}")
-        else:
-            self.e("v_sub_u32 {vt}, {sk}, {vx}")
+        self.e("v_sub_u32 {vt}, {sk}, {vx}")
         self._apply(T, half)
 
     def bit(self, T, ln, half=None, first=False, cmp_lane=None):
         """one tree decision: sym = 2 * sym + (bit == 0), then normalise.  first: sym was 1 (not
         materialised), ln is the constant lane of the root."""
         acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
-        if INTERLEAVE and half is None and BOUND_ON_VALU and not K_ON_VALU:
-            # same instructions as below, ordered so that scalar and vector ones alternate where the
-            # dependencies allow: the 4 waves of a SIMD then less often all want the same pipe
-            e = self.e
-            e("v_lshrrev_b32 {vt}, 11, {range}")
-            e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
-            e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
-            e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
-            e("s_sub_u32 {sr1}, {range}, {sb}")
-            e("s_sub_u32 {sc1}, {code}, {sb}")              # SCC = code < bound  <=>  bit == 0
-            e("s_cselect_b32 {sk}, {c2048}, 31")
-            e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
-            e("s_cselect_b32 {range}, {sb}, {sr1}")
-            e("v_lshrrev_b32 {vt}, 5, {vt}")
-            e("s_cselect_b32 {code}, {code}, {sc1}")
-            e(acc)
-            e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
-            self.norm()
-            return
         self.core(T, ln, half, cmp_lane)
         self.pre_sym()
         self.e(acc)
@@ -402,10 +341,7 @@ class Gen:
         lane of the root when the symbol starts at 1 (then it is not materialised beforehand)."""
         for i in range(nbits):
             first = first_lane is not None and i == 0
-            if DEFER:
-                self.bit_nu(T, first_lane if first else R("sym"), first=first)
-            else:
-                self.bit(T, first_lane if first else R("sym"), first=first)
+            self.bit_nu(T, first_lane if first else R("sym"), first=first)
 
     def tree_update(self, T, final_level, min_level=None):
         """The probability updates of a walked tree, all at once: the final symbol (at heap level
@@ -413,8 +349,6 @@ class Gen:
         decided there (the next bit down); lane L was visited iff sym >> (final_level - level(L)) == L.
         Every visited lane becomes (31 p + K) >> 5, K = 2048 if the bit was 0 (inverted bit 1) else 31.
         min_level: SGPR; only nodes at that heap level or below it were walked in this table."""
-        if not DEFER:
-            return
         e = self.e
         sh, shm1 = {6: ("VSH6", "VSH6M1"), 5: ("VSH5", "VSH5M1"), 4: ("VSH4", "VSH4M1")}[final_level]
         e("v_lshrrev_b32 {va}, {sh}, {sym}", sh=R(sh))
@@ -472,7 +406,7 @@ class Gen:
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False, prof=None, extract=True):
-        if WAITPROF and prof:                              # (uses the prefetch registers: not together with PREFETCH)
+        if WAITPROF and prof:
             self.e("s_memtime s[94:95]")
             self.e("s_waitcnt lgkmcnt(0)")
             self.e("s_mov_b32 s96, s94")
@@ -501,11 +435,6 @@ class Gen:
     def set_guards(self, t):
         """gtop / gdist from len, lim, target, safe_len, mlen (prologue and window refill; clobbers SCC and t)"""
         e = self.e
-        if not GUARD1:
-            e("s_cmpk_gt_u32 {lim}, 63")
-            e("s_cselect_b32 {gtop}, {target}, 0")
-            e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
-            return
         e("s_add_u32 {t}, {safe_len}, 1", t=t)
         e("s_min_u32 {gtop}, {target}, {t}", t=t)
         e("s_cmpk_gt_u32 {lim}, 63")
@@ -647,9 +576,8 @@ class Gen:
             self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
             self.lab(w + "_hfin")
             self.e("s_sub_u32 {mlen}, 0x211, {sym}")      # length = 18 + path = 18 + 255 - (sym - 256)
-            if GUARD1:
-                self.e("s_cmpk_ge_u32 {mlen}, 64")        # copies of 64 bytes and more are done outside the loop
-                self.e("s_cselect_b32 {gdist}, 0, {gdist}")
+            self.e("s_cmpk_ge_u32 {mlen}, 64")        # copies of 64 bytes and more are done outside the loop
+            self.e("s_cselect_b32 {gdist}, 0, {gdist}")
             self.e("s_branch " + self.L(done))
             self.lab(w + "_h3")
             self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
@@ -727,19 +655,17 @@ class Gen:
                 lab("match" + tag + "2")
                 e("s_branch " + L("match2"))
             lab("Otop_slow" + tag)
-            if GUARD1:
-                # a literal decoded at len == out_lim < target: append_literal's error (lzbuffer.rs:206-217); its store fell
-                # outside the slice or beyond out_len.  (len > out_lim >= target: a last match overshot the size, below.)
-                e("s_cmp_lt_u32 {out_lim}, {target}")
-                e("s_cbranch_scc0 " + L("Otop_size" + tag))
-                e("s_cmp_gt_u32 {len}, {out_lim}")
-                e("s_cbranch_scc1 " + L("Xlimit_undo"))
-                lab("Otop_size" + tag)
+            # a literal decoded at len == out_lim < target: append_literal's error (lzbuffer.rs:206-217); its store fell
+            # outside the slice or beyond out_len.  (len > out_lim >= target: a last match overshot the size, below.)
+            e("s_cmp_lt_u32 {out_lim}, {target}")
+            e("s_cbranch_scc0 " + L("Otop_size" + tag))
+            e("s_cmp_gt_u32 {len}, {out_lim}")
+            e("s_cbranch_scc1 " + L("Xlimit_undo"))
+            lab("Otop_size" + tag)
             e("s_cmp_ge_u32 {len}, {target}")
             e("s_cbranch_scc1 " + L("Xdone_size"))
-            if GUARD1:
-                e("s_cmp_gt_u32 {len}, {safe_len}")           # from here on every match looks closer
-                e("s_cselect_b32 {gdist}, 0, {gdist}")
+            e("s_cmp_gt_u32 {len}, {safe_len}")           # from here on every match looks closer
+            e("s_cselect_b32 {gdist}, 0, {gdist}")
             e("s_cmp_eq_u32 {off}, {lim}")                    # reader at EOF: the stream may be finished
             e("s_cbranch_scc0 " + L("top2" + tag))
             lab("Ofin_check" + tag)                           # unknown size: finished when the reader is at EOF
@@ -750,9 +676,6 @@ class Gen:
     def literal_epilogue(self):
         e, L = self.e, self.L
         e("s_xor_b32 {prev}, {sym}, 0x1ff")             # (0x100 | inverted path) -> byte
-        if not GUARD1:
-            e("s_cmp_ge_u32 {len}, {out_lim}")
-            e("s_cbranch_scc1 " + L("Xlimit"))
         e("v_mov_b32 {VT0}, {prev}")
         e("v_or_b32 {VT1}, {len}, {VOOB}")
         if WAITPROF2:
@@ -776,155 +699,6 @@ class Gen:
         e("s_cbranch_scc1 " + L("Orow_swap" + tag))
         self.lab("lit_r" + tag)
         self.row_swap_stub("Orow_swap" + tag, "lit_r" + tag)
-
-    def distance_scalar(self):
-        """decode_distance with the slot arithmetic on the scalar ALU (the round-1 form)"""
-        e, lab, L = self.e, self.lab, self.L
-        e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2
-        e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
-        e("v_mov_b32 {VPS}, " + PS0M2)
-        e("s_set_gpr_idx_off")
-        self.tree_walk(V["VPS"], 6, first_lane="1")
-        self.tree_update(V["VPS"], 6)
-        e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
-        e("v_mov_b32 " + PS0M2 + ", {VPS}")
-        e("s_set_gpr_idx_off")
-        e("s_xor_b32 {t0}, {sym}, 0x7f")                    # pos_slot
-        e("s_cmp_lt_u32 {t0}, 4")
-        e("s_cbranch_scc1 " + L("dist_small"))
-        e("s_lshr_b32 {t1}, {t0}, 1")
-        e("s_add_u32 {t1}, {t1}, -1")                       # num_direct_bits
-        e("s_and_b32 {t2}, {t0}, 1")
-        e("s_cmp_lt_u32 {t0}, 14")
-        e("s_cbranch_scc1 " + L("dist_rev"))
-        # slots >= 14: ndb - 4 direct bits d, then the 4-bit align tree a (m_align, heap from lane 1):
-        #   rep0 = ((2 | slot & 1) << ndb) + (d << 4) + a.  The decoders deliver the inverted values
-        #   d' = 2^(ndb-4) - 1 - d and a' = 15 - a, so rep0 = ((3 + (slot & 1)) << ndb) - ((d' << 4) + a' + 1).
-        e("s_add_u32 {t2}, {t2}, 3")
-        e("s_lshl_b32 {t2}, {t2}, {t1}")
-        e("s_add_u32 {t3}, {t1}, -4")                       # count
-        e("s_mov_b32 {t4}, 0")
-        if JUMP and not PREFETCH:
-            # 26 identical blocks (the most a distance can have), entered so that exactly `count` of them run:
-            # one computed jump instead of a loop with a test per group of four and a tail
-            e("s_getpc_b64 " + JPAIR)
-            lab("direct_pc")
-            e("s_mul_i32 {t5}, {t3}, (" + L("direct_done") + "-" + L("direct_chain") + ")/26")
-            e("s_sub_u32 {t5}, " + L("direct_done") + "-" + L("direct_pc") + ", {t5}")
-            e("s_add_u32 " + JPAIR_LO + ", " + JPAIR_LO + ", {t5}")
-            e("s_addc_u32 " + JPAIR_HI + ", " + JPAIR_HI + ", 0")
-            e("s_setpc_b64 " + JPAIR)
-            lab("direct_chain")
-            for _ in range(26):
-                self.direct_bit(R("t4"))
-        else:
-            lab("direct4")
-            e("s_cmp_lt_u32 {t3}, 4")
-            e("s_cbranch_scc1 " + L("direct_tail"))
-            for _ in range(4):
-                self.direct_bit(R("t4"))
-            e("s_add_u32 {t3}, {t3}, -4")
-            e("s_branch " + L("direct4"))
-            lab("direct_tail")
-            if PREFETCH:
-                # t3 = r direct bits (0..3) and the 4 align bits are still to come: the distance is known to within
-                # 2^(r+4) bytes.  rep0 + 1 lies in (R0 - 2^(r+4), R0] with R0 = t2 - (t4 << (r+4)), so the source starts
-                # in [len - R0, len - R0 + 2^(r+4)): pull those lines towards L2 now with (dummy) scalar loads -- the
-                # copy's vector load, ~100 instructions from here, otherwise pays the full dictionary-read latency.
-                e("s_add_u32 {t5}, {t3}, 4")
-                e("s_lshl_b32 {t5}, {t4}, {t5}")
-                e("s_sub_u32 {t5}, {t2}, {t5}")
-                e("s_sub_u32 {t5}, {len}, {t5}")
-                e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
-                e("s_add_u32 {t6}, {t5}, 64")
-                e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
-                e("s_add_u32 {t6}, {t5}, 0x80")
-                e("s_buffer_load_dword {pf2}, {out_rsrc}, {t6}")
-            e("s_bitcmp1_b32 {t3}, 1")
-            e("s_cbranch_scc0 " + L("direct_t1"))
-            for _ in range(2):
-                self.direct_bit(R("t4"))
-            lab("direct_t1")
-            e("s_bitcmp1_b32 {t3}, 0")
-            e("s_cbranch_scc0 " + L("direct_done"))
-            self.direct_bit(R("t4"))
-        lab("direct_done")
-        self.tree_walk(R("m_align"), 4, first_lane="1")
-        self.tree_update(R("m_align"), 4)
-        e("s_lshl_b32 {t4}, {t4}, 4")
-        e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
-        e("s_brev_b32 {t3}, {t3}")                           # a'
-        e("s_add_u32 {t4}, {t4}, {t3}")
-        e("s_add_u32 {t4}, {t4}, 1")
-        e("s_sub_u32 {rep0}, {t2}, {t4}")
-        e("s_cmp_eq_u32 {rep0}, -1")
-        e("s_cbranch_scc1 " + L("Xmarker"))
-        e("s_branch " + L("copy"))
-        with self.in_cold():
-            lab("dist_small")
-            e("s_mov_b32 {rep0}, {t0}")
-            e("s_branch " + L("copy"))
-        with self.in_cold():
-            # slots 4..11: pos_decoders[result - slot + node] in m_posdec_a, ndb = 1..4 bits;
-            # slots 12, 13: m_posdec_b lanes (slot - 12) * 32 + node, 5 bits
-            lab("dist_rev")
-            e("s_or_b32 {t2}, {t2}, 2")
-            e("s_lshl_b32 {t2}, {t2}, {t1}")                    # result = (2 | (slot & 1)) << ndb
-            e("s_cmp_lt_u32 {t0}, 12")
-            e("s_cbranch_scc0 " + L("dist_rev_b"))
-            e("s_sub_u32 {t6}, {t2}, {t0}")
-            e("s_mov_b32 {sym}, 1")
-            for i in range(1, 5):
-                e("s_add_u32 {ln}, {t6}, {sym}")
-                self.bit(R("m_posdec_a"), R("ln"))
-                if i < 4:
-                    e("s_cmp_eq_u32 {t1}, %d" % i)
-                    e("s_cbranch_scc1 " + L("dist_rev_fin"))
-            lab("dist_rev_fin")
-            e("s_not_b32 {t4}, {sym}")
-            e("s_sub_u32 {t3}, 32, {t1}")
-            e("s_lshl_b32 {t4}, {t4}, {t3}")
-            e("s_brev_b32 {t4}, {t4}")
-            e("s_add_u32 {rep0}, {t2}, {t4}")
-            e("s_branch " + L("copy"))
-            lab("dist_rev_b")
-            e("s_add_u32 {t6}, {t0}, -12")
-            e("s_lshl_b32 {t6}, {t6}, 5")
-            self.reverse_tree_based(R("m_posdec_b"), R("t6"), 5, R("t4"))
-            e("s_add_u32 {rep0}, {t2}, {t4}")
-            e("s_branch " + L("copy"))
-
-    def copy_guards(self):
-        """the round-1 form: separate guards for the distance, the length and the output limit"""
-        e, lab, L = self.e, self.lab, self.L
-        e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cmp_ge_u32 {rep0}, {gdist}")                     # gdist <= min(len, dict_size): beyond it (and for the
-        e("s_cbranch_scc1 " + L("Ocopy_dist"))                # end marker, rep0 = 0xFFFFFFFF), look closer
-        lab("cp_dist_ok")
-        e("s_cmpk_ge_u32 {mlen}, 64")
-        e("s_cbranch_scc1 " + L("Xlz_slow"))
-        e("s_cmp_gt_u32 {len}, {safe_len}")                   # within 273 bytes of the output limit: look closer
-        e("s_cbranch_scc1 " + L("Ocopy_limit"))
-        lab("cp_lim_ok")
-        e("s_cmp_lg_u32 {pend_n}, 0")
-        e("s_cbranch_scc1 " + L("Opend_copy"))
-        lab("cp_a")
-        e("s_sub_u32 {t2}, {len}, {t0}")                      # src = pos - dist
-        e("s_cmp_le_u32 {t0}, {mlen}")
-        e("s_cbranch_scc1 " + L("Operiodic"))
-        e("v_add_u32 {VT0}, {t2}, {v_lane}")
-        lab("cp_b")
-        e("v_cmp_ge_u32 vcc, {mlen}, {v_lane}")               # lanes 0..n: n bytes + the byte after the source
-        e("s_mov_b32 {pend_pos}, {len}")
-        e("s_mov_b32 {pend_n}, {mlen}")
-        e("s_add_u32 {len}, {len}, {mlen}")
-        e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
-        if WAITPROF2:
-            self.prof_begin()
-        e("buffer_load_ubyte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + LOAD_MOD)
-        if WAITPROF2:
-            self.prof_end("c")
-        e("s_branch " + L("topM"))
 
     def copy_guard1(self):
         """LzCircularBuffer::append_lz (lzbuffer.rs:255-281), short and unclipped: one guard, the previous match's store
@@ -1036,21 +810,19 @@ class Gen:
         e("s_movk_i32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
         self.set_guards(R("n0"))
-        if TABLES:
-            self.tables_prologue()
+        self.tables_prologue()
         if PRIO:
             e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD
             if PRIO < 0:
                 self.set_prio(R("prioph"), R("n0"))
-        if DEFER:                                            # per-lane heap level and the shifts tree_update uses
-            e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
-            e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
-            e("v_sub_u32 {VSH6}, 6, {VLEVEL}")
-            e("v_sub_u32 {VSH6M1}, 5, {VLEVEL}")
-            e("v_sub_u32 {VSH5}, 5, {VLEVEL}")
-            e("v_sub_u32 {VSH5M1}, 4, {VLEVEL}")
-            e("v_sub_u32 {VSH4}, 4, {VLEVEL}")
-            e("v_sub_u32 {VSH4M1}, 3, {VLEVEL}")
+        e("v_ffbh_u32 {VLEVEL}, {v_lane}")               # leading zeros (all ones for lane 0)
+        e("v_sub_u32 {VLEVEL}, 31, {VLEVEL}")            # floor(log2(lane)); 32 for lane 0
+        e("v_sub_u32 {VSH6}, 6, {VLEVEL}")
+        e("v_sub_u32 {VSH6M1}, 5, {VLEVEL}")
+        e("v_sub_u32 {VSH5}, 5, {VLEVEL}")
+        e("v_sub_u32 {VSH5M1}, 4, {VLEVEL}")
+        e("v_sub_u32 {VSH4}, 4, {VLEVEL}")
+        e("v_sub_u32 {VSH4M1}, 3, {VLEVEL}")
         # The loop body exists twice up to the literal: "L" after a literal (state < 7, nothing pending,
         # prev at hand: a literal here is a plain one) and "M" after a match (state >= 7: a literal here is
         # a matched one and first completes the pending match).
@@ -1065,20 +837,14 @@ class Gen:
         self.literal_row("L")
         e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
         e("s_max_i32 {state}, {state}, 0")
-        if DEFER:                   # nodes 1..63 -> u0
-            self.tree_walk(R("u0"), 6, first_lane="1")
-            self.tree_update(R("u0"), 6)
-            with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
-                for i in range(1, 6):   # only the levels from pl0 on were walked in u0
-                    lab("plain%d" % i)
-                    self.bit_nu(R("u0"), R("sym"))
-                self.tree_update(R("u0"), 6, min_level=R("pl0"))
-                e("s_branch " + L("plain6"))
-        else:
-            for i in range(6):
-                if i:
-                    lab("plain%d" % i)
-                self.bit(R("u0"), "1" if i == 0 else R("sym"), first=i == 0)
+        self.tree_walk(R("u0"), 6, first_lane="1")  # nodes 1..63 -> u0
+        self.tree_update(R("u0"), 6)
+        with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
+            for i in range(1, 6):   # only the levels from pl0 on were walked in u0
+                lab("plain%d" % i)
+                self.bit_nu(R("u0"), R("sym"))
+            self.tree_update(R("u0"), 6, min_level=R("pl0"))
+            e("s_branch " + L("plain6"))
         lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
         self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
         lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
@@ -1108,17 +874,11 @@ class Gen:
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 7, 10")
         # ---- decode_distance (lzma.rs:563-592)
-        if TABLES:
-            self.distance_tables()
-        else:
-            self.distance_scalar()
+        self.distance_tables()
 
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
         lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
-        if GUARD1:
-            self.copy_guard1()
-        else:
-            self.copy_guards()
+        self.copy_guard1()
 
         # ================= after a match =================
         self.symbol_top("M")
@@ -1173,7 +933,7 @@ class Gen:
                     e(acc)
                     self.post_known(T, m != 0, half=m)
                     e("ds_write_b128 {VA}, " + MROW)
-                    if DEFER and i + 1 < 6:
+                    if i + 1 < 6:
                         e("s_mov_b32 {pl0}, %d" % (i + 1))
                     self.norm(to="plain%d" % (i + 1), kind="lit")
                 if i < 6:
@@ -1260,12 +1020,6 @@ class Gen:
         e("s_mov_b32 {rep1}, {rep0}")
         e("s_mov_b32 {rep0}, {t0}")
         lab("rep_len")
-        if PREFETCH:                                          # the distance is known before the length is decoded
-            e("s_add_u32 {t5}, {rep0}, 1")
-            e("s_sub_u32 {t5}, {len}, {t5}")
-            e("s_buffer_load_dword {pf0}, {out_rsrc}, {t5}")
-            e("s_add_u32 {t6}, {t5}, 64")
-            e("s_buffer_load_dword {pf1}, {out_rsrc}, {t6}")
         self.len_decode(1, "len1_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 8, 11")
@@ -1274,9 +1028,8 @@ class Gen:
         # ================= out-of-line helpers =================
         with self.in_cold():
             lab("Operiodic")                                  # source index = lane % dist (exact: lane < 64)
-            if GUARD1:
-                e("s_add_u32 {t0}, {rep0}, 1")
-                e("s_add_u32 {t2}, {t2}, -1")
+            e("s_add_u32 {t0}, {rep0}, 1")
+            e("s_add_u32 {t2}, {t2}, -1")
             e("v_cvt_f32_u32 {VT1}, {t0}")
             e("v_rcp_f32 {VT1}, {VT1}")
             e("v_cvt_f32_u32 {VT2}, {v_lane}")
@@ -1289,24 +1042,19 @@ class Gen:
             e("s_branch " + L("cp_b"))
 
             lab("Ocopy_dist")                                 # append_lz's two distance errors, in the reference's order
-            if TABLES:                                        # (only a new distance can be the marker, lzma.rs:372-382: a
-                e("s_cmp_eq_u32 {rep0}, -1")                  #  rep never is, decoding stops at the first one)
-                e("s_cbranch_scc1 " + L("Xmarker"))
-            if GUARD1:
-                e("s_add_u32 {t0}, {rep0}, 1")
+            e("s_cmp_eq_u32 {rep0}, -1")                  #  rep never is, decoding stops at the first one)
+            e("s_cbranch_scc1 " + L("Xmarker"))
+            e("s_add_u32 {t0}, {rep0}, 1")
             e("s_cmp_gt_u32 {t0}, {dict_size}")
             e("s_cbranch_scc1 " + L("Xlz_dist_dict"))
             e("s_cmp_gt_u32 {t0}, {len}")
             e("s_cbranch_scc1 " + L("Xlz_dist_out"))
-            if GUARD1:
-                e("s_cmpk_ge_u32 {mlen}, 64")
-                e("s_cbranch_scc1 " + L("Xlz_slow"))
-                e("s_cmp_gt_u32 {len}, {safe_len}")           # within 273 bytes of the output limit
-                e("s_cbranch_scc1 " + L("Ocopy_limit"))
-                e("s_min_u32 {gdist}, {len}, {dict_size}")    # the bound was stale
-                e("s_branch " + L("cp_lim_ok"))
-            else:
-                e("s_branch " + L("cp_dist_ok"))
+            e("s_cmpk_ge_u32 {mlen}, 64")
+            e("s_cbranch_scc1 " + L("Xlz_slow"))
+            e("s_cmp_gt_u32 {len}, {safe_len}")           # within 273 bytes of the output limit
+            e("s_cbranch_scc1 " + L("Ocopy_limit"))
+            e("s_min_u32 {gdist}, {len}, {dict_size}")    # the bound was stale
+            e("s_branch " + L("cp_lim_ok"))
             lab("Ocopy_limit")                                # (the output resource starts at dict_base: pos = len)
             e("s_add_u32 {t2}, {len}, {mlen}")
             e("s_cbranch_scc1 " + L("Xlz_slow"))
