@@ -1,0 +1,28 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/b15
+mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/gputests.txt 2>&1
+tail -5 $O/gputests.txt
+BENCH="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- $BENCH > $O/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?"
+done
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1
+echo "trace rc=$?"
+find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+python - <<'PY'
+import csv,glob
+from collections import defaultdict
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    fs=glob.glob("gpurun_out/b15/pmc_%s/*/*counter_collection.csv"%c)
+    if not fs: print(c,"no csv"); continue
+    agg=defaultdict(float); dur={}
+    for r in csv.DictReader(open(fs[0])):
+        if "decode_fast_asm" not in r["Kernel_Name"]: continue
+        agg[r["Counter_Name"]]+=float(r["Counter_Value"]); dur[r["Counter_Name"]]=int(r["End_Timestamp"])-int(r["Start_Timestamp"])
+    print(c, dict(agg), dur)
+PY
+cat $O/kernel_stats.csv | head -3
