@@ -61,6 +61,7 @@ struct milzma_ctx {
   uint8_t* pend_out = nullptr;
   std::vector<milzma_unit> pend_units;  // (the caller's array need not outlive the call)
   PinBuf pin_results;
+  hipStream_t copy_stream = nullptr;    // chunked staging copies of the whole-file batch entry points
   float last_ms = 0.f;
   uint32_t last_launches = 0;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
@@ -138,6 +139,69 @@ void parallel_for(size_t n, F fn) {
   for (auto& th : pool) th.join();
 }
 
+// A large device -> pinned-host copy cut in chunks with an event behind each, so that host threads can start on the
+// front of the buffer while the back is still crossing PCIe (and the mirror image for host -> device).
+struct ChunkedCopy {
+  static constexpr size_t kChunk = size_t(64) << 20;
+  milzma_ctx* ctx = nullptr;
+  std::vector<hipEvent_t> ev;
+  bool ok = true;
+
+  bool stream_ready(milzma_ctx* c) {
+    ctx = c;
+    if (!ctx->copy_stream && !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate"))
+      return false;
+    return true;
+  }
+  // device [0, bytes) -> host, asynchronously; wait_until(end) blocks until [0, end) has arrived
+  bool start_d2h(milzma_ctx* c, void* host, const void* dev, size_t bytes) {
+    if (!stream_ready(c)) return ok = false;
+    for (size_t o = 0; o < bytes; o += kChunk) {
+      const size_t n = std::min(kChunk, bytes - o);
+      hipEvent_t e = nullptr;
+      if (!hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t*>(host) + o, static_cast<const uint8_t*>(dev) + o, n, hipMemcpyDeviceToHost,
+                                      ctx->copy_stream),
+                  "D2H output") ||
+          !hip_ok(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate") ||
+          !hip_ok(ctx, hipEventRecord(e, ctx->copy_stream), "hipEventRecord")) {
+        if (e) (void)hipEventDestroy(e);
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        return ok = false;
+      }
+      ev.push_back(e);
+    }
+    return true;
+  }
+  bool wait_until(size_t end) const {  // callable from several threads
+    if (!ok) return false;
+    if (end == 0 || ev.empty()) return true;
+    const size_t k = std::min((end - 1) / kChunk, ev.size() - 1);
+    return hipEventSynchronize(ev[k]) == hipSuccess;
+  }
+  ~ChunkedCopy() {
+    if (ctx && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+// Host -> device staging in groups: `fill(g)` writes group g's bytes [lo, hi) of the pinned buffer (on the host threads),
+// then that range is sent; the next group is filled while this one crosses PCIe.  bounds: groups + 1 ascending offsets.
+template <class F>
+bool staged_h2d(milzma_ctx* ctx, void* dev, const void* host, const std::vector<size_t>& bounds, F fill) {
+  ChunkedCopy cc;
+  if (!cc.stream_ready(ctx)) return false;
+  for (size_t g = 0; g + 1 < bounds.size(); g++) {
+    fill(g);
+    const size_t lo = bounds[g], hi = bounds[g + 1];
+    if (hi > lo && !hip_ok(ctx,
+                           hipMemcpyAsync(static_cast<uint8_t*>(dev) + lo, static_cast<const uint8_t*>(host) + lo, hi - lo,
+                                          hipMemcpyHostToDevice, ctx->copy_stream),
+                           "H2D input"))
+      return false;
+  }
+  return hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize");
+}
+
 }  // namespace
 
 extern "C" uint32_t milzma_abi_version(void) { return MILZMA_ABI_VERSION; }
@@ -189,6 +253,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   pin_release(ctx->pin_results);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -962,10 +1027,22 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     return finish_alone();
   }
   uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-  parallel_for(units.size(), [&](size_t k) {
-    memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
-  });
-  if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return fail_all();
+  {
+    // eight groups of streams: the gather of one group overlaps the transfer of the one before
+    const size_t groups = std::min<size_t>(8, units.size());
+    std::vector<size_t> first(groups + 1), bounds(groups + 1);
+    for (size_t g = 0; g <= groups; g++) {
+      first[g] = units.size() * g / groups;
+      bounds[g] = g == groups ? in_total : size_t(units[first[g]].in_off);
+    }
+    if (!staged_h2d(ctx, ctx->in.p, hin, bounds, [&](size_t g) {
+          parallel_for(first[g + 1] - first[g], [&](size_t k0) {
+            const size_t k = first[g] + k0;
+            memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+          });
+        }))
+      return fail_all();
+  }
   const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
   // Rounds: units whose guessed output slice was too small (unknown-size streams) run again, together,
   // with four times the room; the input stays on the device.
@@ -980,9 +1057,10 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       out_bytes += size_t(sub[j].out_cap);
     }
     std::vector<milzma_result> r(sub.size());
+    ChunkedCopy d2h;  // the output comes back in chunks; a stream is handed over as soon as its slice has arrived
     if (!pin_reserve(ctx, ctx->pin_out, out_bytes) || !dev_reserve(ctx, ctx->out, out_bytes + 512) ||
         milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), nullptr) != MILZMA_OK ||
-        !hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_bytes, hipMemcpyDeviceToHost), "D2H output")) {
+        !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes)) {
       for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
       return MILZMA_INFRA_ERROR;
     }
@@ -994,6 +1072,10 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         return;
       }
       const uint32_t i = owner[todo[j]];
+      if (!d2h.wait_until(size_t(sub[j].out_off + sub[j].out_cap))) {
+        out_fail(&outs[i], MILZMA_INFRA_ERROR, "D2H output failed");
+        return;
+      }
       finish_stream(r[j], kind, hout + sub[j].out_off, size_t(sub[j].out_cap), hdr[i], &outs[i]);
     });
     std::vector<uint32_t> next;
@@ -1460,6 +1542,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   std::vector<milzma_result> res(nu);
   const uint8_t* hout = nullptr;
   const uint8_t* parts = nullptr;
+  ChunkedCopy d2h;
   if (nu) {
     // Decoding ahead is an optimisation: if its memory cannot be had (or anything else goes wrong here) the walk below
     // decodes every block on demand and each file still gets the reference's verdict.
@@ -1471,10 +1554,25 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
           !dev_reserve(ctx, ctx->out, out_total + 512) || !dev_reserve(ctx, ctx->crc, parts_bytes))
         return false;
       uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-      parallel_for(n, [&](size_t i) {
-        if (planned[i]) memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
-      });
-      if (!hip_ok(ctx, hipMemcpy(ctx->in.p, hin, in_total, hipMemcpyHostToDevice), "H2D input")) return false;
+      {
+        // eight groups of files: the gather of one group overlaps the transfer of the one before
+        std::vector<uint32_t> pf;
+        for (uint32_t i = 0; i < n; i++)
+          if (planned[i]) pf.push_back(i);
+        const size_t groups = std::min<size_t>(8, pf.size());
+        std::vector<size_t> first(groups + 1), bounds(groups + 1);
+        for (size_t g = 0; g <= groups; g++) {
+          first[g] = pf.size() * g / groups;
+          bounds[g] = g == groups ? in_total : file_in_off[pf[first[g]]];
+        }
+        if (!staged_h2d(ctx, ctx->in.p, hin, bounds, [&](size_t g) {
+              parallel_for(first[g + 1] - first[g], [&](size_t k0) {
+                const uint32_t i = pf[first[g] + k0];
+                memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
+              });
+            }))
+          return false;
+      }
       if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK) return false;
       // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
       return hip_ok(ctx,
@@ -1482,7 +1580,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
                                      static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, nullptr),
                     "crc kernel launch") &&
              hip_ok(ctx, hipMemcpy(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost), "D2H crc parts") &&
-             hip_ok(ctx, hipMemcpy(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost), "D2H output");
+             d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_total);  // in chunks: the walks below start on the first ones
     };
     if (ahead()) {
       hout = static_cast<const uint8_t*>(ctx->pin_out.p);
@@ -1510,7 +1608,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
           const size_t k = it->second;
           const milzma_result& r = res[k];
           if (r.status == MILZMA_ST_OK && r.in_consumed == units[k].in_len && !(r.chunks & 0x80000000u) &&
-              r.out_len <= units[k].out_cap) {
+              r.out_len <= units[k].out_cap && d2h.wait_until(size_t(units[k].out_off + r.out_len))) {
             p->res = r;
             p->data = hout + units[k].out_off;
             crc_fold(parts + k * kCrcPartsBytes, r.out_len, &p->crc32, &p->crc64);
