@@ -78,6 +78,9 @@ PRIO_TIME = int(os.environ.get("MILZMA_GEN_PRIO_TIME", "21"))  # k > 0: rotate o
 # a scalar instruction per byte costs 3x what a vector instruction does.  FORMB: comma list of where it is used
 # (tree = deferred-update tree walks, single = is_match / is_rep / choice ..., lit = literal levels 6-7 and matched literals).
 FORMB = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_FORMB", "tree"))))
+# range >> 11 on the scalar ALU (s_lshr_b32, then v_mul with a scalar operand) instead of as a dependent vector instruction:
+# list of site kinds (tree, single, lit)
+R11S = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_R11S", ""))))
 # the "range < 2^24" test on the scalar ALU (s_cmp_lt_u32 + s_cbranch_scc1) instead of the vector ALU (v_cmp + s_cbranch_vccnz):
 # list of site kinds (tree, single, lit, direct), or 1 = everywhere
 NORM_S = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_NORM_S", "1"))))
@@ -88,7 +91,7 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pad="s69", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         c2017="s90", c2048="s91", pad="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
@@ -239,12 +242,13 @@ class Gen:
         0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
         self.pad()
         if ("lit" if half is not None else "single") in FORMB or formb:
-            self.e("v_lshrrev_b32 {vt}, 11, {range}")
+            rs = ("lit" if half is not None else "single") in R11S
+            self.e("s_lshr_b32 {st}, {range}, 11" if rs else "v_lshrrev_b32 {vt}, 11, {range}")
             if half == 0:
                 self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
             elif half == 1:
                 self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
-            self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
+            self.e("v_mul_u32_u24 {vb}, {t}, {src}", t=R("st") if rs else R("vt"), src=T if half is None else R("vx"))
             self.e("v_sub_u32 {vr}, {range}, {vb}")
             self.e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)      # (bound, code)
             self.e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)        # range - bound
@@ -253,12 +257,13 @@ class Gen:
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
             return
         # form A: every lane computes the bound of its own probability; the one that is needed is read out
-        self.e("v_lshrrev_b32 {vt}, 11, {range}")
+        rs = ("lit" if half is not None else "single") in R11S
+        self.e("s_lshr_b32 {st}, {range}, 11" if rs else "v_lshrrev_b32 {vt}, 11, {range}")
         if half == 0:
             self.e("v_and_b32 {vx}, 0xffff, {T}", T=T)
         elif half == 1:
             self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
-        self.e("v_mul_u32_u24 {vb}, {vt}, {src}", src=T if half is None else R("vx"))
+        self.e("v_mul_u32_u24 {vb}, {t}, {src}", t=R("st") if rs else R("vt"), src=T if half is None else R("vx"))
         self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))  # (also keeps the
         self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)  # v_readlane one instruction away from vb's producer)
         self.e("s_sub_u32 {sr1}, {range}, {sb}")
@@ -315,8 +320,12 @@ class Gen:
         e = self.e
         self.pad()
         if "tree" in FORMB:
-            e("v_lshrrev_b32 {vt}, 11, {range}")
-            e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
+            if "tree" in R11S:
+                e("s_lshr_b32 {st}, {range}, 11")
+                e("v_mul_u32_u24 {vb}, {st}, {T}", T=T)
+            else:
+                e("v_lshrrev_b32 {vt}, 11, {range}")
+                e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
             e("v_sub_u32 {vr}, {range}, {vb}")
             e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)           # (bound, code)
             e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)             # range - bound
