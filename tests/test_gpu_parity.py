@@ -638,3 +638,29 @@ def test_decode_units_async_overlaps_and_matches_sync(ctx):
         assert res[i].status == M.ST_OK and host[i << 18:(i + 1) << 18] == plains[i]
     with pytest.raises(M.InfraError):
         ctx.decode_units_wait(n)  # nothing in flight
+
+
+def test_differential_fuzz_round(ctx):
+    """one round of experiments/parity_fuzz.py (1260 damaged / odd .lzma, LZMA2 and .xz inputs and option combinations
+    through the batch and single-file entry points) against the oracle; profiles/r02_parity_fuzz.txt records the
+    75 000-case search it comes from (fuzz/fuzz_targets/decompress_*.rs, compare_*.rs of the reference)"""
+    import importlib.util
+    import random as _random
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("parity_fuzz", os.path.join(root, "experiments", "parity_fuzz.py"))
+    pf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pf)
+    rng = _random.Random(20260927)
+    lz = pf.pool_lzma(rng)
+    l2, xz = pf.pool_lzma2_xz(rng)
+    bad = 0
+    cases = [pf.damage(rng, pf.edit_lzma_header(rng, rng.choice(lz)) if rng.random() < 0.5 else rng.choice(lz), 13) for _ in range(600)]
+    for comp, d in zip(cases, ctx.lzma_batch(cases)):
+        bad += not pf.same("lzma", comp, d, orc.lzma_decompress(comp))
+    cases = [pf.damage(rng, rng.choice(l2), 0) for _ in range(300)]
+    for comp, d in zip(cases, ctx.lzma2_batch(cases)):
+        bad += not pf.same("lzma2", comp, d, orc.lzma2_decompress(comp))
+    cases = [pf.damage(rng, rng.choice(xz), 0) for _ in range(300)]
+    for comp, d in zip(cases, ctx.xz_batch(cases)):
+        bad += not pf.same("xz", comp, d, orc.xz_decompress(comp))
+    assert bad == 0
