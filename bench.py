@@ -307,6 +307,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu_line = cpu_baseline(1 << 20 if mode == "xz" else size, args.kind, dict_size, cores)
 
+    if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())  # before the process group exists: RCCL binds to it
     D.init()
     # tile the distinct items over the n slots (each slot still reads its own copy from HBM)
     n_units = n * upi
