@@ -47,7 +47,7 @@ thread_local std::string g_create_error;
 struct milzma_ctx {
   int device = 0;
   std::string err;
-  DevBuf units, order, results, scratch, in, out, crc;
+  DevBuf units, order, results, scratch, in, out, crc, flags;  // flags: 64 words, one per launch in flight (last-block flags)
   PinBuf pin_in, pin_out, pin_small;
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -249,6 +249,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   dev_release(ctx->in);
   dev_release(ctx->out);
   dev_release(ctx->crc);
+  dev_release(ctx->flags);
   pin_release(ctx->pin_in);
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
@@ -315,7 +316,8 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     hipEvent_t e0 = ctx->ev_pool[size_t(ctx->ev_used) * 2], e1 = ctx->ev_pool[size_t(ctx->ev_used) * 2 + 1];
     if (!hip_ok(ctx, hipEventRecord(e0, stream), "hipEventRecord")) return false;
     const hipError_t le = cls == kFast || cls == kFastLc4
-                              ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4)
+                              ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
+                                            static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
                               : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
@@ -392,7 +394,7 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
 
   if (!dev_reserve(ctx, ctx->units, size_t(n) * sizeof(milzma_unit)) ||
       !dev_reserve(ctx, ctx->order, size_t(n) * 2 * sizeof(uint32_t)) ||
-      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)) ||
+      !dev_reserve(ctx, ctx->results, size_t(n) * sizeof(milzma_result)) || !dev_reserve(ctx, ctx->flags, 64 * sizeof(uint32_t)) ||
       !pin_reserve(ctx, ctx->pin_results, size_t(n) * (sizeof(milzma_result) + sizeof(uint32_t))))
     return fail();
   // (the order array is staged in page-locked memory behind the results so that its upload is asynchronous too)

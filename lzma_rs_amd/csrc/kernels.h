@@ -27,7 +27,7 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 
 // The lane-resident-model kernel (symbol loop in gfx950 asm): lc + lp <= 3 at 16 waves per CU, or (lc4) lc + lp <= 4 at 9.
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad = 0, bool lc4 = false);
+                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag);
 
 // Partial CRCs (64 chunks per unit) of the units' decoded output; see crc_units.hip.h.
 struct CrcParts;

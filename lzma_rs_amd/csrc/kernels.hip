@@ -36,13 +36,20 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 }
 
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4) {
+                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag) {
   if (n == 0) return hipSuccess;
+  // d_flag: a device word per launch that the launch's last block raises: the waves rotate their priorities (finish
+  // together) only once no block is waiting for a slot any more; until then staggered finishes refill slots early
+  // (5120 streams: 13.5 vs 11.2 GB/s).  A launch that is a whole number of rounds rotates from the start (8192: 17.2 vs 16.2).
+  const uint32_t resident = lc4 ? 256u * 9u : 256u * 16u;
+  if (hipError_t e = hipMemsetAsync(d_flag, n % resident == 0 ? 1 : 0, sizeof(uint32_t), stream); e != hipSuccess) return e;
   // lds_pad: unused dynamic LDS (MILZMA_LDS_PAD, tuning only): what an LDS-resident window of that size would do to occupancy
   if (lc4)
-    hipLaunchKernelGGL(decode_fast_asm_kernel<16>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results);
+    hipLaunchKernelGGL(decode_fast_asm_kernel<16>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results,
+                       d_flag);
   else
-    hipLaunchKernelGGL(decode_fast_asm_kernel<8>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results);
+    hipLaunchKernelGGL(decode_fast_asm_kernel<8>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results,
+                       d_flag);
   return hipGetLastError();
 }
 

@@ -151,6 +151,8 @@ class Program:
             last = ops[3].split()
             assert "offen" in last, text
             ops = ops[:3] + [last[0]]
+        if op == "s_load_dword":
+            ops = ops[:2] + [ops[2].split()[0]]
         if op.startswith("ds_"):
             ops = [o for o in ops if not o.startswith("offset:")] + [o.split(":")[1] for o in ops if o.startswith("offset:")]
         enc = [self._operand(o) for o in ops]
@@ -201,6 +203,10 @@ class AsmLoop:
                 s_next = (s_next + 3) & ~3
                 self.regmap[name] = "s[%d:%d]" % (s_next, s_next + 3)
                 s_next += 4
+            elif name == "flagptr":
+                s_next = (s_next + 1) & ~1
+                self.regmap[name] = "s[%d:%d]" % (s_next, s_next + 1)
+                s_next += 2
             else:
                 self.regmap[name] = "s%d" % s_next
                 s_next += 1
@@ -261,11 +267,16 @@ class AsmLoop:
         if out_cap is None:
             out_cap = unpacked_size if unpacked_size is not None else len(payload) * 64 + 4096
         in_len = len(payload)
-        IN0 = 64
+        IN0 = 64  # (bytes 0..3 of the emulated memory: the "last block has started" flag, set)
         in_span = (in_len + 63 + 128) & ~63
         OUT0 = IN0 + in_span + 64
         mem = np.zeros(OUT0 + out_cap + 512, dtype=np.uint8)
         mem[IN0:IN0 + in_len] = np.frombuffer(bytes(payload), dtype=np.uint8)
+        mem[0] = 1
+        if "flagptr" in self.regmap:
+            i = self._sidx("flagptr")
+            self.L.emu_set_s(self.h, i, 0)
+            self.L.emu_set_s(self.h, i + 1, 0)
         self._mem = mem
         self.L.emu_set_mem(self.h, mem.ctypes.data, mem.size)
         self.L.emu_set_hwreg(self.h, hw_slot)

@@ -38,10 +38,10 @@ struct Ins {
   X(s_bfm_b32) X(s_flbit_i32_b32) X(s_ff1_i32_b32) X(s_ff1_i32_b64) X(s_bcnt1_i32_b32) X(s_cmp_eq_u32)                 \
   X(s_cmp_lg_u32) X(s_cmp_gt_u32) X(s_cmp_ge_u32) X(s_cmp_lt_u32) X(s_cmp_le_u32) X(s_cmp_lt_i32) X(s_cmp_gt_i32)      \
   X(s_cmpk_eq_u32) X(s_cmpk_lg_u32) X(s_cmpk_gt_u32) X(s_cmpk_ge_u32) X(s_cmpk_lt_u32) X(s_cmpk_le_u32)                \
-  X(s_bitcmp1_b32) X(s_bitcmp0_b32) X(s_bitcmp1_b64) X(s_branch) X(s_cbranch_scc0) X(s_cbranch_scc1)                   \
+  X(s_bitset1_b32) X(s_bitcmp1_b32) X(s_bitcmp0_b32) X(s_bitcmp1_b64) X(s_branch) X(s_cbranch_scc0) X(s_cbranch_scc1)                   \
   X(s_cbranch_vccnz) X(s_cbranch_vccz) X(s_cbranch_execz) X(s_nop) X(s_waitcnt) X(s_getpc_b64) X(s_setpc_b64)          \
   X(s_call_b64) X(s_set_gpr_idx_on) X(s_set_gpr_idx_off) X(s_addk_i32) X(s_sleep) X(s_abs_i32) X(s_setprio)  \
-  X(s_getreg_b32) X(s_memtime) X(s_memrealtime)                         \
+  X(s_getreg_b32) X(s_memtime) X(s_memrealtime) X(s_load_dword)                         \
   X(v_mov_b32) X(v_readlane_b32) X(v_readfirstlane_b32) X(v_writelane_b32) X(v_lshrrev_b32) X(v_lshlrev_b32)           \
   X(v_ashrrev_i32) X(v_add_u32) X(v_sub_u32) X(v_subrev_u32) X(v_and_b32) X(v_or_b32) X(v_xor_b32)                     \
   X(v_mul_u32_u24) X(v_mad_u32_u24) X(v_mul_lo_u32) X(v_cndmask_b32) X(v_cmp_lt_u32) X(v_cmp_eq_u32) X(v_cmp_gt_u32)   \
@@ -258,6 +258,7 @@ long run(Emu& e, int start, long max_steps) {
       case OP_s_cmpk_ge_u32: e.scc = rs(e, I.a[0]) >= (I.a[1].val & 0xFFFFu); break;
       case OP_s_cmpk_lt_u32: e.scc = rs(e, I.a[0]) < (I.a[1].val & 0xFFFFu); break;
       case OP_s_cmpk_le_u32: e.scc = rs(e, I.a[0]) <= (I.a[1].val & 0xFFFFu); break;
+      case OP_s_bitset1_b32: ws(e, I.a[0], rs(e, I.a[0]) | (1u << (rs(e, I.a[1]) & 31u))); break;
       case OP_s_bitcmp1_b32: e.scc = (rs(e, I.a[0]) >> (rs(e, I.a[1]) & 31u)) & 1u; break;
       case OP_s_bitcmp0_b32: e.scc = !((rs(e, I.a[0]) >> (rs(e, I.a[1]) & 31u)) & 1u); break;
       case OP_s_bitcmp1_b64: e.scc = uint32_t((rs64(e, I.a[0]) >> (rs(e, I.a[1]) & 63u)) & 1u); break;
@@ -268,6 +269,13 @@ long run(Emu& e, int start, long max_steps) {
       case OP_s_cbranch_vccz: if (e.vcc == 0) { next = int(I.a[0].val); e.taken[pc]++; } break;
       case OP_s_cbranch_execz: break;  // EXEC is never zero here
       case OP_s_getreg_b32: ws(e, I.a[0], e.hwreg); break;  // (whatever field is asked for: the value the test set)
+      case OP_s_load_dword: {  // sdst, sbase (pair: address in the emulated memory), offset
+        const uint64_t a = rs64(e, I.a[1]) + I.a[2].val;
+        uint32_t x = 0;
+        if (a + 4 > e.mem_size) { e.err = "s_load_dword outside the emulated memory"; break; }
+        memcpy(&x, e.mem + a, 4);
+        ws(e, I.a[0], x);
+      } break;
       case OP_s_memtime:
       case OP_s_memrealtime: ws64(e, I.a[0], e.executed + uint64_t(steps)); break;
       case OP_s_setprio:

@@ -71,6 +71,10 @@ PAD_B = int(os.environ.get("MILZMA_GEN_PAD_B", "0"))
 # with the youngest.  PRIO = k > 0: every window refill sets s_setprio ((len >> k) + wave slot) & 3, so that the four waves
 # of a SIMD take turns at every priority and finish together.  PRIO = -1: static priority = wave slot (diagnostic).
 PRIO = int(os.environ.get("MILZMA_GEN_PRIO", "12"))
+# PRIO_LAST: rotate only once the launch's last block has started (a flag it sets, polled at every window refill): while
+# blocks are still waiting for a slot, waves that finish staggered (oldest first) free slots early and the CU stays full
+# -- 6144 streams (1.5 rounds): 14.2 GB/s without rotation, 12.9 with; for one round (<= 4096 streams) the flag is up at once.
+PRIO_LAST = os.environ.get("MILZMA_GEN_PRIO_LAST", "1") == "1"
 PRIO_TIME = int(os.environ.get("MILZMA_GEN_PRIO_TIME", "21"))  # k > 0: rotate on the shader clock ((s_memtime >> k) + slot) instead of on len
 # Decision "form B": range and code live in the adjacent pair s[66:67]; the vector ALU also delivers range - bound, both are
 # read into scalar pairs and ONE s_cselect_b64 picks (bound, code) or (range - bound, code - bound): 3 scalar + 5 vector
@@ -135,7 +139,7 @@ OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_p
                "m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b",
                "m_rlen_mid_b"]
 OPS_IN_S = ["out_lim", "safe_len", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
-            "out_rsrc", "ldsbase"]
+            "out_rsrc", "ldsbase", "flagptr"]
 OPS_IN_V = ["v_lane"]
 FIXED_OPERANDS = {"range": "s66", "code": "s67"}   # an aligned pair, for s_cselect_b64
 RC = "s[66:67]"
@@ -1092,11 +1096,26 @@ class Gen:
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
             if PRIO > 0 and PRIO_TIME:
+                if PRIO_LAST:
+                    # bit 8 of prioph: "the launch's last block has started" has been seen.  Until then the flag is polled at
+                    # every 16th refill only (a coherent scalar load of one word that 4096 waves share is slow when hammered).
+                    e("s_bitcmp1_b32 {prioph}, 8")
+                    e("s_cbranch_scc1 " + L("rot"))
+                    e("s_and_b32 {n1}, {wbase}, 0x3c0")
+                    e("s_cbranch_scc1 " + L("norot"))
+                    e("s_load_dword {clk_t}, {flagptr}, 0x0 glc")
+                    e("s_waitcnt lgkmcnt(0)")
+                    e("s_cmp_eq_u32 {clk_t}, 0")
+                    e("s_cbranch_scc1 " + L("norot"))
+                    e("s_bitset1_b32 {prioph}, 8")
+                    lab("rot")
                 e("s_memtime s[94:95]")
                 e("s_waitcnt lgkmcnt(0)")
                 e("s_lshr_b64 s[94:95], s[94:95], %d" % PRIO_TIME)
                 e("s_add_u32 {n1}, s94, {prioph}")
                 self.set_prio(R("n1"), R("n0"))
+                if PRIO_LAST:
+                    lab("norot")
             elif PRIO > 0:
                 e("s_lshr_b32 {n1}, {len}, %d" % PRIO)       # (n0 / n1: the only temporaries free wherever a refill happens)
                 e("s_add_u32 {n1}, {n1}, {prioph}")
