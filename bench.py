@@ -236,6 +236,82 @@ def cpu_baseline(size, kind, dict_size, cores):
                                 "independent, faster CPU decoder)"}}
 
 
+
+def tile_units(M, units_d, blob_len, n, distinct, upi, size):
+    """tile the distinct items over the n slots (each slot still reads its own copy from HBM).
+    Returns (units ctypes array, compressed payload bytes of the tiled batch)."""
+    units = (M.Unit * (n * upi))()
+    comp_total = 0
+    for k in range(n):
+        for j in range(upi):
+            src = units_d[(k % distinct) * upi + j]
+            u = M.Unit()
+            ctypes.memmove(ctypes.byref(u), ctypes.byref(src), ctypes.sizeof(M.Unit))
+            u.in_off = src.in_off + (k // distinct) * blob_len
+            u.out_off = src.out_off - (k % distinct) * size + k * size
+            units[k * upi + j] = u
+            comp_total += src.in_len
+    return units, comp_total
+
+
+def verify_units(M, ctx, units, res, d_out, stream, crcs_d, n, upi, distinct, size, mode):
+    """(bad, verified): status, length and the GPU-computed CRC-32 of EVERY unit against the regenerated plaintext's"""
+    c32, _ = ctx.crc_units(units, res, d_out.data_ptr(), stream)
+    bad = verified = 0
+    for k in range(n):
+        for j in range(upi):
+            i = k * upi + j
+            want_len = units[i].out_cap if mode == "xz" else size
+            if res[i].status != M.ST_OK or res[i].out_len != want_len or c32[i] != crcs_d[(k % distinct) * upi + j]:
+                bad += 1
+            verified += 1
+    return bad, verified
+
+
+def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
+    """One of the other single-GPU BASELINE configs, measured exactly like the headline (device-resident input and output,
+    K timed steps of milzma_decode_units, every unit CRC-verified afterwards); returned as a dict for `other_configs`."""
+    cfg = CONFIGS[name]
+    mode = "xz" if name == "xz" else "lzma"
+    n, size, dict_size, distinct = cfg["streams"], cfg["size"], cfg["dict"], cfg["distinct"]
+    units_d, blob_d, _, gen_s = build_batch(distinct, size, "text", dict_size, 0, procs, mode)
+    crcs_d = build_batch.crcs
+    upi = len(units_d) // distinct
+    units, comp_total = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
+    reps = (n + distinct - 1) // distinct
+    h_in = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
+    d_in = (h_in.repeat(reps) if reps > 1 else h_in).to(dev)
+    out_bytes = n * size
+    d_out = torch.empty(out_bytes + 512, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, ms, launches = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), stream)
+        kernel_ms.append(ms)
+    torch.cuda.synchronize(dev)
+    step_s = (time.perf_counter() - t0) / steps
+    d_out.zero_()
+    res, _, _ = ctx.decode_units(units, d_in.data_ptr(), d_out.data_ptr(), stream)
+    bad, verified = verify_units(M, ctx, units, res, d_out, stream, crcs_d, n, upi, distinct, size, mode)
+    k_ms = statistics.median(kernel_ms)
+    alg = comp_total + out_bytes
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    what = ("%d .xz files of %d B (1 MiB blocks, LZMA2 with stored chunks, CRC64): %d LZMA2 units" % (n, size, n * upi)
+            if mode == "xz" else "%d independent %d-byte .lzma streams" % (n, size))
+    return {"workload": "configs[%d]: %s, lc3/lp0/pb2, dict %d, class text" % (cfg["idx"], what, dict_size),
+            "value": round(out_bytes / step_s / 1e9, 4), "unit": "GB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
+            "bit_exact": bad == 0, "verified_units": verified, "distinct_items": distinct, "generation_s": round(gen_s, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg}}
+
+
 # ---- launching -----------------------------------------------------------------------------------------
 def self_launch(n_gpus):
     """--gpus N outside torchrun: one rank per GPU of this node, or a loud failure"""
@@ -274,6 +350,10 @@ def main():
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1: ship every rank's compressed input from rank 0 and gather the decoded output back over "
                          "the process group, timed separately (scatter_gather)")
+    ap.add_argument("--other-configs", default="auto",
+                    help="comma list of further single-GPU BASELINE configs measured after the headline and attached as "
+                         "`other_configs` (auto = dict8m,xz on a default 1-GPU headline run; none = skip)")
+    ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--dry-run", action="store_true", help="everything up to (not including) the first decode: no GPU needed")
     args = ap.parse_args()
 
@@ -311,21 +391,9 @@ def main():
     if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() > 0:
         torch.cuda.set_device(local_rank % torch.cuda.device_count())  # before the process group exists: RCCL binds to it
     D.init()
-    # tile the distinct items over the n slots (each slot still reads its own copy from HBM)
     n_units = n * upi
-    units = (M.Unit * n_units)()
     reps = (n + distinct - 1) // distinct
-    stride = len(blob_d)
-    comp_total = 0
-    for k in range(n):
-        for j in range(upi):
-            src = units_d[(k % distinct) * upi + j]
-            u = M.Unit()
-            ctypes.memmove(ctypes.byref(u), ctypes.byref(src), ctypes.sizeof(M.Unit))
-            u.in_off = src.in_off + (k // distinct) * stride
-            u.out_off = src.out_off - (k % distinct) * size + k * size
-            units[k * upi + j] = u
-            comp_total += src.in_len
+    units, comp_total = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
     out_bytes_rank = n * size
     h_in_one = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
     h_in = h_in_one.repeat(reps) if reps > 1 else h_in_one
@@ -385,14 +453,7 @@ def main():
     if not args.no_verify:
         d_out.zero_()
         res, _, _ = step()
-        c32, _ = ctx.crc_units(units, res, d_out.data_ptr(), stream)
-        for k in range(n):
-            for j in range(upi):
-                i = k * upi + j
-                want_len = units[i].out_cap if mode == "xz" else size
-                if res[i].status != M.ST_OK or res[i].out_len != want_len or c32[i] != crcs_d[(k % distinct) * upi + j]:
-                    bad += 1
-                verified += 1
+        bad, verified = verify_units(M, ctx, units, res, d_out, stream, crcs_d, n, upi, distinct, size, mode)
     else:
         bad = sum(1 for r in res if r.status != M.ST_OK)
     bad_total = int(D.sum_over_ranks(bad, dev))
@@ -418,6 +479,19 @@ def main():
     pcie = None
     if args.pcie:
         pcie = pcie_inclusive(ctx, M, torch, dev, units, h_in, d_in, d_out, n_units, out_bytes_rank)
+
+    others = {}
+    want = args.other_configs
+    if want == "auto":
+        default_run = (world == 1 and args.config == "lzma64k" and args.kind == "text" and not args.streams and not args.size
+                       and not args.dict and args.props == "3,0,2")
+        want = "dict8m,xz" if default_run else "none"
+    if want != "none":
+        del d_in, d_out
+        torch.cuda.empty_cache()
+        for name in want.split(","):
+            others[name] = run_other_config(name, args, M, torch, dev, ctx, procs, args.other_steps, 1)
+            bad_total += 0 if others[name]["bit_exact"] else 1
 
     total_out = out_bytes_rank * world
     step_s = elapsed / args.steps
@@ -496,6 +570,8 @@ def main():
         if scalar is not None:
             line["roofline_issue"] = scalar
         line["cpu_baseline"] = cpu_line
+        if others:
+            line["other_configs"] = others
         if pcie is not None:
             line["pcie_inclusive"] = pcie
         if scatter_line is not None:

@@ -351,23 +351,31 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
     ctx->err = "a batch is already in flight on this context: call milzma_decode_units_wait first";
     return MILZMA_INFRA_ERROR;
   }
+  if (n && !units) {
+    ctx->err = "null units";
+    return MILZMA_INFRA_ERROR;
+  }
   ctx->last_ms = 0.f;
   ctx->last_launches = 0;
   ctx->ev_used = 0;
   ctx->pend_n = n;
   ctx->pending = true;
   if (n == 0) return MILZMA_OK;
-  if (!units) {
-    ctx->pending = false;
-    ctx->err = "null units";
-    return MILZMA_INFRA_ERROR;
-  }
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  // Copies and kernels may already be queued when a later step fails: they still reference pend_units, the pinned
+  // result buffer and the device buffers, so the stream is drained before the batch is declared gone.
   const auto fail = [&]() {
+    const std::string why = ctx->err;
+    (void)hipStreamSynchronize(stream);
+    ctx->err = why;
+    ctx->ev_used = 0;
     ctx->pending = false;
     return MILZMA_INFRA_ERROR;
   };
-  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail();
-  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) {
+    ctx->pending = false;
+    return MILZMA_INFRA_ERROR;
+  }
   ctx->pend_stream = stream;
   ctx->pend_in = static_cast<const uint8_t*>(d_in);
   ctx->pend_out = static_cast<uint8_t*>(d_out);
@@ -422,13 +430,13 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
     ctx->err = "no batch in flight on this context";
     return MILZMA_INFRA_ERROR;
   }
-  ctx->pending = false;
   const uint32_t n = ctx->pend_n;
-  if (n == 0) return MILZMA_OK;
-  if (!results) {
+  if (n && !results) {  // (the batch stays in flight: the caller can still wait for it with a real buffer)
     ctx->err = "null results";
     return MILZMA_INFRA_ERROR;
   }
+  ctx->pending = false;
+  if (n == 0) return MILZMA_OK;
   hipStream_t stream = ctx->pend_stream;
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") ||
       !collect_kernel_ms(ctx))
@@ -1019,6 +1027,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   // page-locked staging (PCIe at link speed), filled and emptied by several host threads
   auto fail_all = [&]() {
     for (uint32_t i : owner) infra(ctx, &outs[i]);
+    for (uint32_t i : alone) single(i);  // (decoded, or given their own infrastructure error: never left as an empty success)
     return MILZMA_INFRA_ERROR;
   };
   if (!ctx) return fail_all();
@@ -1064,6 +1073,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), nullptr) != MILZMA_OK ||
         !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes)) {
       for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
+      finish_alone();
       return MILZMA_INFRA_ERROR;
     }
     const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
@@ -1598,6 +1608,10 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   const PayloadFn live_unlocked = live_decoder(ctx);
   const PayloadFn live = [&](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
     std::lock_guard<std::mutex> lock(ctx->mu);
+    // An on-demand decode launches on the null stream and writes ctx->out from offset 0 -- the buffer the chunked D2H of the
+    // blocks decoded ahead is still reading on the (non-blocking) copy stream.  Let that copy finish first: from then on
+    // every planned payload is on the host and ctx->out is free.
+    if (hout && ctx->copy_stream && !hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize")) return false;
     return live_unlocked(in, in_len, cap_hint, p);
   };
   parallel_for(n, [&](size_t i) {

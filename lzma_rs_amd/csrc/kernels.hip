@@ -35,13 +35,33 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
   return hipGetLastError();
 }
 
+// Blocks of the fast kernel the current device holds at once (occupancy API x CU count, asked once per instantiation;
+// the data-sheet figures -- 256 CUs x 16, or x 9 for the LC4 instantiation -- if the API fails).  Only decides whether the
+// priority rotation starts with the launch: a wrong value costs time, never correctness.
+static uint32_t resident_blocks(bool lc4, uint32_t lds_pad) {
+  static uint32_t cached[2] = {0, 0};
+  if (lds_pad == 0 && cached[lc4]) return cached[lc4];
+  uint32_t r = lc4 ? 256u * 9u : 256u * 16u;
+  int dev = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  const hipError_t e = lc4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<16>, int(kWave), lds_pad)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<8>, int(kWave), lds_pad);
+  if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      prop.multiProcessorCount > 0)
+    r = uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
+  else
+    (void)hipGetLastError();
+  if (lds_pad == 0) cached[lc4] = r;
+  return r;
+}
+
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                        milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag) {
   if (n == 0) return hipSuccess;
   // d_flag: a device word per launch that the launch's last block raises: the waves rotate their priorities (finish
   // together) only once no block is waiting for a slot any more; until then staggered finishes refill slots early
   // (5120 streams: 13.5 vs 11.2 GB/s).  A launch that is a whole number of rounds rotates from the start (8192: 17.2 vs 16.2).
-  const uint32_t resident = lc4 ? 256u * 9u : 256u * 16u;
+  const uint32_t resident = resident_blocks(lc4, lds_pad);
   if (hipError_t e = hipMemsetAsync(d_flag, n % resident == 0 ? 1 : 0, sizeof(uint32_t), stream); e != hipSuccess) return e;
   // lds_pad: unused dynamic LDS (MILZMA_LDS_PAD, tuning only): what an LDS-resident window of that size would do to occupancy
   if (lc4)
