@@ -129,7 +129,7 @@ def test_generated_asm_loop_is_current(tmp_path):
 def test_asm_loop_wait_states():
     """gfx940-family hazards hipcc would pad for but inline asm must respect itself (both measured to matter or
     listed for the family): a VALU write of a VGPR needs one wait state before a v_readlane of it; a VALU write
-    of VCC needs two before a VALU read of VCC.  Straight-line check over the generated text (labels and
+    of VCC (or of an SGPR pair used as a lane mask) needs two before a VALU read of it.  Straight-line check over the generated text (labels and
     branches end a run: a taken branch is more than two wait states)."""
     inc = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "fast_loop_asm.inc")).read()
     runs = re.findall(r'#define MILZMA_FAST_LOOP_TEXT_\w+ \\\n((?:  ".*" \\\n)+)', inc)
@@ -149,14 +149,15 @@ def test_asm_loop_wait_states():
                 src = args[1]
                 assert not (prev and prev[-1][2] and prev[-1][0] == src), "v_readlane right after the VALU write of %s" % src
                 checked += 1
-            reads_vcc = op.startswith("v_") and "vcc" in args[1:] and not op.startswith("v_cmp")
-            if reads_vcc:
+            # lane masks: vcc, or an SGPR pair written by a VOP3 compare (deferred tree updates, the pending match's store)
+            masks = [a for a in args[1:] if a == "vcc" or re.fullmatch(r"s\[\d+:\d+\]", a)]
+            if op.startswith("v_") and masks and not op.startswith("v_cmp"):
                 for back in prev[-2:]:
-                    assert not back[1], "VALU read of vcc %d instruction(s) after its VALU write: %s" % (1, l)
+                    assert back[1] not in masks, "VALU read of %s within two instructions of its VALU write: %s" % (back[1], l)
                 checked += 1
             is_valu = op.startswith("v_")
-            writes_vcc = op.startswith("v_cmp") and args[0] == "vcc"
-            prev.append((args[0] if args else "", writes_vcc, is_valu))
+            writes_mask = args[0] if op.startswith("v_cmp") else None
+            prev.append((args[0] if args else "", writes_mask, is_valu))
             if op.startswith("s_cbranch"):
                 pass  # the fall-through continues the run
     assert checked > 800

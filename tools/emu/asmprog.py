@@ -143,6 +143,8 @@ class Program:
     def _encode(self, idx, text):
         parts = text.split(None, 1)
         op = parts[0]
+        if op.endswith("_e64"):     # (explicit VOP3 encoding: same semantics)
+            op = op[:-4]
         ops = split_operands(parts[1]) if len(parts) > 1 else []
         if op in ("s_waitcnt", "s_nop", "s_sleep", "s_setprio", "s_set_gpr_idx_off"):
             ops = []

@@ -88,6 +88,16 @@ R11S = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_R11S", "")))
 # the "range < 2^24" test on the scalar ALU (s_cmp_lt_u32 + s_cbranch_scc1) instead of the vector ALU (v_cmp + s_cbranch_vccnz):
 # list of site kinds (tree, single, lit, direct), or 1 = everywhere
 NORM_S = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_NORM_S", "1"))))
+# normalisation stub: one s_lshl_b64 of the (range, code) pair instead of two 32-bit shifts (range's top byte is zero there)
+NORM64 = os.environ.get("MILZMA_GEN_NORM64", "1") == "1"
+# Shadow scheduling (round 3, experiments/microbench/shadow_slots.hip): the first scalar instruction after a v_readlane issues
+# ~19 cycles after it; up to four independent VECTOR instructions placed between the v_readlane(s) of a decision and its s_sub are
+# free for a lone wave and cost 5.4 cycles instead of 10 at 4 waves per SIMD (scalar ones gain nothing there).  DEFER: which
+# probability updates are queued and emitted into the NEXT decisions' shadows instead of after their own decision:
+#   single = the update of is_match / is_rep / choice ... decisions and of immediate-update tree levels (3 instructions),
+#   tree   = the once-per-walk update of the literal / pos_slot trees (7 instructions).  SHADOW: instructions per shadow.
+DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
+SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
 if "1" in NORM_S:
     NORM_S = {"tree", "single", "lit", "direct"}
 
@@ -95,15 +105,17 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         c2017="s90", c2048="s91", pad="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         pad="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
+DM = "s[90:91]"     # lane mask of a deferred tree update (the constants 2017 / 2048 that used to live there are VGPRs now)
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
 JBASE = "s[64:65]"  # address of Lbase (set once per entry): jump targets are table offsets from it
 RET = "s[92:93]"  # return address of the window refill subroutine
 _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt=93, VR=94, VL16=95, VOOB=96, VKTOP=97, vx=98,
            VLANE64=99, VLANE128=100, VLANE192=101, vb=102, VSH6=103, VSH6M1=104, VSH5=105, VSH5M1=106, VSH4=107, VSH4M1=108,
-           VLEVEL=109, va=110, vr=112, VLANEM1=113)
+           VLEVEL=109, va=110, vr=112, VLANEM1=113,
+           DVT=114, DVA=115, DVX=116, c2017=117, c2048=118)  # temporaries of deferred updates; the constants 2017 and 2048
 if PAD_V:
     _V0["vpad"] = 111
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
@@ -125,7 +137,7 @@ def set_layout(lc4):
 
 
 set_layout(False)
-CLOBBER_S = sorted(set(S.values()) | {"s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ the refill return address)
+CLOBBER_S = sorted(set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ DM, the refill return address)
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
@@ -168,15 +180,65 @@ class Gen:
         self.main, self.cold, self.cold2, self.stubs = [], [], [], []  # (cold2: out-of-line code of code that is itself in `cold`)
         self.cur = self.main
         self.uid = 0
+        # deferred vector instructions (see DEFER): a FIFO of (text, reads_sym, reads_vcc); `reach`: the previous instruction can
+        # fall through to the next one; lstate: label -> the queue every path must arrive with (checked at each branch / label)
+        self.q = []
+        self.reach = True
+        self.lstate = {}
+
+    ANY_STATE = ("Xeof", "Xmatch_dist_dict", "Xmatch_dist_out")   # decoding ends there with an error: the model no longer matters
+
+    def _st(self):
+        return tuple(self.q)
+
+    def _edge(self, name, conditional):
+        if name in self.ANY_STATE:
+            return
+        reg = self.lstate.get(name)
+        if reg is None:
+            self.lstate[name] = self._st()
+        elif reg != self._st():
+            if not conditional and reg == ():
+                self.flush()
+            else:
+                raise AssertionError("branch to %s with deferred updates %r, the label expects %r" % (name, self._st(), reg))
 
     def e(self, fmt, **kw):
         """emit one instruction; {x} is replaced by the register of operand/temporary x"""
         out = fmt
         for n in set(re.findall(r"\{(\w+)\}", fmt)):
             out = out.replace("{%s}" % n, kw[n] if n in kw else R(n))
+        ops = out.replace(",", " ").split()
+        op = ops[0]
+        if op in ("s_branch", "s_call_b64", "s_setpc_b64") or op.startswith("s_cbranch"):
+            tgt = re.search(r"L(\w+)%=", out)
+            if tgt and op != "s_call_b64":
+                self._edge(tgt.group(1), op != "s_branch")
+        elif len(ops) > 1 and not kw.get("_queued"):
+            # a queued instruction must be emitted before something it reads is overwritten
+            if ops[1] == S["sym"] and any(x[1] for x in self.q):
+                raise AssertionError("sym is overwritten while a deferred update still reads it: " + out)
+            if ops[1] == "vcc" and op.startswith("v_") and any(x[2] for x in self.q):
+                raise AssertionError("vcc is overwritten while a deferred update still reads it: " + out)
         self.cur.append("  " + out)
+        if op in ("s_branch", "s_setpc_b64"):
+            self.reach = False
 
     def lab(self, name):
+        reg = self.lstate.get(name)
+        if self.reach:
+            if reg is None:
+                self.lstate[name] = self._st()
+            elif reg != self._st():
+                if reg == ():
+                    self.flush()
+                else:
+                    raise AssertionError("falling into %s with deferred updates %r, the label expects %r" % (name, self._st(), reg))
+        else:
+            if reg is None:
+                reg = self.lstate[name] = ()
+            self.q = list(reg)
+        self.reach = True
         self.cur.append("L%s%%=:" % name)
 
     @staticmethod
@@ -188,15 +250,45 @@ class Gen:
         return "%s%d" % (prefix, self.uid)
 
     class _Into:
-        def __init__(self, g, lst):
-            self.g, self.lst = g, lst
+        """emit into another list (out-of-line code): starts unreachable with an empty queue (its first label sets the state)"""
+        def __init__(self, g, lst, keep=False):
+            self.g, self.lst, self.keep = g, lst, keep
 
         def __enter__(self):
-            self.saved = self.g.cur
+            self.saved = (self.g.cur, self.g.q, self.g.reach)
             self.g.cur = self.lst
+            if not self.keep:
+                self.g.q, self.g.reach = [], False
 
         def __exit__(self, *a):
-            self.g.cur = self.saved
+            if (not a or a[0] is None) and not self.keep:
+                assert not self.g.reach, "out-of-line code falls off its end"
+            self.g.cur, self.g.q, self.g.reach = self.saved
+
+    # ---- deferred vector instructions ----------------------------------------------------------------------------
+    def defer(self, fmt, reads_sym=False, reads_vcc=False, **kw):
+        out = fmt
+        for n in set(re.findall(r"\{(\w+)\}", fmt)):
+            out = out.replace("{%s}" % n, kw[n] if n in kw else R(n))
+        self.q.append((out, reads_sym, reads_vcc))
+
+    def shadow(self, n):
+        """up to n queued instructions, here"""
+        k = 0
+        while self.q and k < n:
+            self.e(self.q.pop(0)[0], _queued=True)
+            k += 1
+        return k
+
+    def flush(self):
+        while self.q:
+            self.e(self.q.pop(0)[0], _queued=True)
+
+    def flush_reads(self, sym=False, vcc=False):
+        """everything up to the last queued instruction that reads sym / vcc"""
+        last = max([i for i, x in enumerate(self.q) if (sym and x[1]) or (vcc and x[2])], default=-1)
+        for _ in range(last + 1):
+            self.e(self.q.pop(0)[0], _queued=True)
 
     def in_cold(self):
         return Gen._Into(self, self.cold)
@@ -206,6 +298,8 @@ class Gen:
         """RangeDecoder::normalize (rangecoder.rs:59-69) as a check + out-of-line stub.
         `to`: label to continue at (default: fall through)."""
         k = self.new("N")
+        if to is not None and self.q and self.lstate.get(to, ()) == ():
+            self.flush()          # (the stub branches to `to` as well: both must arrive with what the label expects)
         if kind in NORM_S:
             self.e("s_cmp_lt_u32 {range}, 0x1000000")
             self.e("s_cbranch_scc1 " + self.L(k))
@@ -223,8 +317,11 @@ class Gen:
             self.e("s_cmp_eq_u32 {off}, {lim}")
             self.e("s_cbranch_scc1 " + self.L("Xeof"))
             self.e("v_readlane_b32 {n1}, {winb}, {off}")
-            self.e("s_lshl_b32 {range}, {range}, 8")
-            self.e("s_lshl_b32 {code}, {code}, 8")
+            if NORM64:   # range < 2^24 here: its top byte is zero, so one 64-bit shift of the (range, code) pair moves both
+                self.e("s_lshl_b64 " + RC + ", " + RC + ", 8")
+            else:
+                self.e("s_lshl_b32 {range}, {range}, 8")
+                self.e("s_lshl_b32 {code}, {code}, 8")
             self.e("s_or_b32 {code}, {code}, {n1}")
             self.e("s_add_u32 {off}, {off}, 1")
             self.e("s_bitcmp1_b32 {off}, 6")
@@ -243,8 +340,11 @@ class Gen:
     def core(self, T, ln, half=None, cmp_lane=None, formb=False):
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
-        0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`."""
+        0 / 1 = low / high 16 bits (then vx = this lane's probability).  vcc = mask of lane `ln`.
+        Queued vector instructions (DEFER) go into the shadow of the v_readlane(s); those that read the previous decision's
+        vcc all go before this decision's own v_cmp_eq."""
         self.pad()
+        mask = lambda: self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
         if ("lit" if half is not None else "single") in FORMB or formb:
             rs = ("lit" if half is not None else "single") in R11S
             self.e("s_lshr_b32 {st}, {range}, 11" if rs else "v_lshrrev_b32 {vt}, 11, {range}")
@@ -256,7 +356,9 @@ class Gen:
             self.e("v_sub_u32 {vr}, {range}, {vb}")
             self.e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)      # (bound, code)
             self.e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)        # range - bound
-            self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))
+            self.shadow(SHADOW)
+            self.flush_reads(vcc=True)
+            mask()
             self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
             return
@@ -268,8 +370,15 @@ class Gen:
         elif half == 1:
             self.e("v_lshrrev_b32 {vx}, 16, {T}", T=T)
         self.e("v_mul_u32_u24 {vb}, {t}, {src}", t=R("st") if rs else R("vt"), src=T if half is None else R("vx"))
-        self.e("v_cmp_eq_u32 vcc, {ln}, {cl}", ln=ln, cl=cmp_lane or R("v_lane"))  # (also keeps the
-        self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)  # v_readlane one instruction away from vb's producer)
+        if self.q:                # (one instruction between vb's producer and the v_readlane of it: a queued one, else the mask)
+            self.shadow(1)
+            self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
+            self.shadow(SHADOW - 1)
+            self.flush_reads(vcc=True)
+            mask()
+        else:
+            mask()
+            self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
         self.e("s_sub_u32 {sr1}, {range}, {sb}")
         self.e("s_sub_u32 {sc1}, {code}, {sb}")          # SCC = code < bound  <=>  bit == 0
         self.e("s_cselect_b32 {range}, {sb}, {sr1}")
@@ -284,10 +393,16 @@ class Gen:
 
     # p += (K - p) >> 5 with K = 2048 for a 0 bit and 31 for a 1 bit (the arithmetic shift makes the second
     # -(p >> 5)); for an unpacked probability this is (31 * p + K) >> 5: one v_mad and one shift.
-    def post_known(self, T, bit0, half=None):
+    def post_known(self, T, bit0, half=None, defer=True):
         """probability update when the bit value is known from the branch taken"""
         if half is None:
-            self.e("v_mad_u32_u24 {vt}, {T}, 31, %s" % ("{c2048}" if bit0 else "31"), T=T)
+            k = "{c2048}" if bit0 else "31"
+            if defer and "single" in DEFER:      # into the next decision's shadow (its v_cmp_eq comes after these)
+                self.defer("v_mad_u32_u24 {DVT}, {T}, 31, %s" % k, T=T)
+                self.defer("v_lshrrev_b32 {DVT}, 5, {DVT}")
+                self.defer("v_cndmask_b32 {T}, {T}, {DVT}, vcc", reads_vcc=True, T=T)
+                return
+            self.e("v_mad_u32_u24 {vt}, {T}, 31, %s" % k, T=T)
             self.e("v_lshrrev_b32 {vt}, 5, {vt}")
             self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
             return
@@ -296,11 +411,16 @@ class Gen:
 
     def pre_sym(self):
         """scalar part of the update of a tree decision; call while SCC = (bit == 0)"""
-        self.e("s_cselect_b32 {sk}, {c2048}, 31")
+        self.e("s_cselect_b32 {sk}, 0x800, 31")
 
-    def post_sym(self, T, half=None):
+    def post_sym(self, T, half=None, defer=True):
         """probability update of a tree decision (the symbol's new low bit is 1 if the bit was 0)"""
         if half is None:
+            if defer and "single" in DEFER:      # (sk stays valid: the next decision's pre_sym comes after its shadow)
+                self.defer("v_mad_u32_u24 {DVT}, {T}, 31, {sk}", T=T)
+                self.defer("v_lshrrev_b32 {DVT}, 5, {DVT}")
+                self.defer("v_cndmask_b32 {T}, {T}, {DVT}, vcc", reads_vcc=True, T=T)
+                return
             self.e("v_mad_u32_u24 {vt}, {T}, 31, {sk}", T=T)
             self.e("v_lshrrev_b32 {vt}, 5, {vt}")
             self.e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
@@ -308,14 +428,14 @@ class Gen:
         self.e("v_sub_u32 {vt}, {sk}, {vx}")
         self._apply(T, half)
 
-    def bit(self, T, ln, half=None, first=False, cmp_lane=None):
+    def bit(self, T, ln, half=None, first=False, cmp_lane=None, defer=True):
         """one tree decision: sym = 2 * sym + (bit == 0), then normalise.  first: sym was 1 (not
         materialised), ln is the constant lane of the root."""
         acc = "s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}"
         self.core(T, ln, half, cmp_lane)
         self.pre_sym()
         self.e(acc)
-        self.post_sym(T, half)
+        self.post_sym(T, half, defer=defer)
         self.norm()
 
     def bit_nu(self, T, ln, first=False):
@@ -333,11 +453,14 @@ class Gen:
             e("v_sub_u32 {vr}, {range}, {vb}")
             e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)           # (bound, code)
             e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)             # range - bound
+            self.shadow(SHADOW)
+            self.flush_reads(sym=True)                               # (sym changes below)
             e("s_sub_u32 {sc1}, {code}, {range}")                    # SCC = code < bound  <=>  bit == 0
             e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
             e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
             self.norm(kind="tree")
             return
+        self.flush()
         e("v_lshrrev_b32 {vt}, 11, {range}")
         e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
         e("s_nop 0")  # gfx940: one wait state between a VALU write and the v_readlane of it (measured: without it every stream decodes wrongly)
@@ -356,7 +479,7 @@ class Gen:
             first = first_lane is not None and i == 0
             self.bit_nu(T, first_lane if first else R("sym"), first=first)
 
-    def tree_update(self, T, final_level, min_level=None):
+    def tree_update(self, T, final_level, min_level=None, defer=False):
         """The probability updates of a walked tree, all at once: the final symbol (at heap level
         `final_level`, inverted-bit path) names the visited node of every level (its prefixes) and the bit
         decided there (the next bit down); lane L was visited iff sym >> (final_level - level(L)) == L.
@@ -364,6 +487,19 @@ class Gen:
         min_level: SGPR; only nodes at that heap level or below it were walked in this table."""
         e = self.e
         sh, shm1 = {6: ("VSH6", "VSH6M1"), 5: ("VSH5", "VSH5M1"), 4: ("VSH4", "VSH4M1")}[final_level]
+        if defer and min_level is None and "tree" in DEFER:
+            # queued for the shadows of the decisions that follow: own temporaries (DVA, DVX) and mask (DM), the instructions
+            # that read sym first
+            d = self.defer
+            d("v_lshrrev_b32 {DVA}, {sh}, {sym}", reads_sym=True, sh=R(sh))
+            d("v_bfe_u32 {DVX}, {sym}, {sh}, 1", reads_sym=True, sh=R(shm1))
+            d("v_cmp_eq_u32_e64 " + DM + ", {DVA}, {v_lane}")
+            d("v_mad_u32_u24 {DVX}, {DVX}, {c2017}, 31")
+            d("v_mad_u32_u24 {DVA}, {T}, 31, {DVX}", T=T)
+            d("v_lshrrev_b32 {DVA}, 5, {DVA}")
+            d("v_cndmask_b32_e64 {T}, {T}, {DVA}, " + DM, T=T)
+            return
+        self.flush()
         e("v_lshrrev_b32 {va}, {sh}, {sym}", sh=R(sh))
         e("v_bfe_u32 {vx}, {sym}, {sh}, 1", sh=R(shm1))
         e("v_cmp_eq_u32 vcc, {va}, {v_lane}")
@@ -376,12 +512,12 @@ class Gen:
             e("s_and_b64 vcc, vcc, " + MPAIR)
         e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
 
-    def decide(self, T, ln, taken, cmp_lane=None):
+    def decide(self, T, ln, taken, cmp_lane=None, defer=True):
         """a decision that ends in a branch: falls through for a 0 bit, jumps to `taken` for a 1 bit.
         The code at `taken` must start with self.taken(T)."""
         self.core(T, ln, cmp_lane=cmp_lane)
         self.e("s_cbranch_scc0 " + self.L(taken))
-        self.post_known(T, True)
+        self.post_known(T, True, defer=defer)
         self.norm()
 
     def decide_by_reg(self, regs, ln, taken_pfx, join):
@@ -390,23 +526,23 @@ class Gen:
         e, L = self.e, self.L
         e("s_cmp_lt_u32 {ln}, 64", ln=ln)
         e("s_cbranch_scc0 " + L(taken_pfx + "_hi"))
-        self.decide(R(regs[0]), ln, taken_pfx + "_ta")   # (v_readlane takes the index's low 6 bits; the update mask compares
+        self.decide(R(regs[0]), ln, taken_pfx + "_ta", defer=False)   # (v_readlane takes the index's low 6 bits; the update mask compares
         self.lab(join)                                    #  it with lane + 64 / lane + 128 for the other two registers)
         with self.in_cold():
             self.lab(taken_pfx + "_hi")
             e("s_cmp_lt_u32 {ln}, 0x80", ln=ln)
             e("s_cbranch_scc0 " + L(taken_pfx + "_hi2"))
-            self.decide(R(regs[1]), ln, taken_pfx + "_tb", cmp_lane=V["VLANE64"])
-            e("s_branch " + L(join))
+            self.decide(R(regs[1]), ln, taken_pfx + "_tb", cmp_lane=V["VLANE64"], defer=False)   # (the three registers' paths
+            e("s_branch " + L(join))                                                             #  join: nothing queued there)
             self.lab(taken_pfx + "_hi2")
-            self.decide(R(regs[2]), ln, taken_pfx + "_tc", cmp_lane=V["VLANE128"])
+            self.decide(R(regs[2]), ln, taken_pfx + "_tc", cmp_lane=V["VLANE128"], defer=False)
             e("s_branch " + L(join))
             for tag, reg in zip("abc", regs):
                 self.lab(taken_pfx + "_t" + tag)
-                self.taken(R(reg), to=taken_pfx + "2")
+                self.taken(R(reg), to=taken_pfx + "2", defer=False)
 
-    def taken(self, T, to=None):
-        self.post_known(T, False)
+    def taken(self, T, to=None, defer=True):
+        self.post_known(T, False, defer=defer)
         self.norm(to)
 
     def direct_bit(self, acc):
@@ -432,7 +568,7 @@ class Gen:
         # (gfx940 family: a VALU write of VCC / an SGPR wants 2 wait states before a VALU read of it, hence
         #  the order: the v_cmp that writes vcc is never followed directly by the v_cndmask that reads it)
         self.e("s_waitcnt vmcnt(0)")
-        self.e("v_cmp_gt_u32 vcc, {pend_n}, {v_lane}")
+        self.e("v_cmp_gt_u32_e64 " + MPAIR + ", {pend_n}, {v_lane}")   # (not vcc: a deferred update may still read it)
         self.e("v_add_u32 {VT0}, {pend_pos}, {v_lane}")
         if extract:
             if not have_t6:
@@ -441,7 +577,7 @@ class Gen:
             self.e("v_readlane_b32 {mb}, {pend_val}, {pend_n}")
         else:                                              # (keeps the v_cmp two instructions away from the v_cndmask)
             self.e("s_nop 0")
-        self.e("v_cndmask_b32 {VT0}, -1, {VT0}, vcc")
+        self.e("v_cndmask_b32_e64 {VT0}, -1, {VT0}, " + MPAIR)
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
         self.e("s_mov_b32 {pend_n}, 0")
 
@@ -586,14 +722,14 @@ class Gen:
             self.bit(R(p + "_h1"), R("sym"), cmp_lane=V["VLANE64"])
             self.e("s_bitcmp1_b32 {sym}, 6")
             self.e("s_cbranch_scc1 " + self.L(w + "_h3"))
-            self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"])
+            self.bit(R(p + "_h2"), R("sym"), cmp_lane=V["VLANE128"], defer=False)
             self.lab(w + "_hfin")
             self.e("s_sub_u32 {mlen}, 0x211, {sym}")      # length = 18 + path = 18 + 255 - (sym - 256)
             self.e("s_cmpk_ge_u32 {mlen}, 64")        # copies of 64 bytes and more are done outside the loop
             self.e("s_cselect_b32 {gdist}, 0, {gdist}")
             self.e("s_branch " + self.L(done))
             self.lab(w + "_h3")
-            self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"])
+            self.bit(R(p + "_h3"), R("sym"), cmp_lane=V["VLANE192"], defer=False)
             self.e("s_branch " + self.L(w + "_hfin"))
 
     def reverse_tree_based(self, T, base_reg, nbits, out):
@@ -699,6 +835,27 @@ class Gen:
         e("s_add_u32 {len}, {len}, 1")
         e("s_branch " + L("topL"))
 
+    def literal_tail(self, cold):
+        """levels 6 and 7 of a plain literal and its epilogue.  cold: the copy the matched literal's mismatch paths enter (labels
+        plain6 / plain7; no deferred updates); else the hot one (level 6's update rides in level 7's shadow)."""
+        e, lab, L = self.e, self.lab, self.L
+        pfx = "c" if cold else ""
+        if cold:
+            lab("plain6")           # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
+        self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"], defer=not cold)
+        if cold:
+            lab("plain7")           # nodes 128..191 -> u2, 192..255 -> u3
+        e("s_bitcmp1_b32 {sym}, 6")          # (set for a byte with bit 7 clear: the fall-through serves ASCII)
+        e("s_cbranch_scc0 " + L(pfx + "plain7_lo"))
+        self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"], defer=False)
+        if not cold:
+            lab("lit_done")
+        self.literal_epilogue()
+        with self.in_cold():
+            lab(pfx + "plain7_lo")
+            self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"], defer=False)
+            self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
+
     def literal_row(self, tag):
         e, L = self.e, self.L
         if self.lp0:
@@ -744,6 +901,13 @@ class Gen:
         if WAITPROF2:
             self.prof_end("c")                               # falls through into the top after a match
 
+    def posslot_writeback(self):
+        """the walked pos_slot tree (VPS, its update complete) back to the register of its len_state (t5 = len_state + 2)"""
+        self.flush()
+        self.e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
+        self.e("v_mov_b32 " + PS0M2 + ", {VPS}")
+        self.e("s_set_gpr_idx_off")
+
     def distance_tables(self):
         """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
         for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
@@ -753,21 +917,21 @@ class Gen:
         e("v_mov_b32 {VPS}, " + PS0M2)
         e("s_set_gpr_idx_off")
         self.tree_walk(V["VPS"], 6, first_lane="1")
-        self.tree_update(V["VPS"], 6)
-        e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
-        e("v_mov_b32 " + PS0M2 + ", {VPS}")
-        e("s_set_gpr_idx_off")
-        e("v_readlane_b32 {t2}, {tbl_a}, {sym}")
-        e("v_readlane_b32 {t5}, {tbl_b}, {sym}")
+        self.tree_update(V["VPS"], 6, defer=True)            # (queued: emitted in the shadows of the align walk; the tree goes
+        e("v_readlane_b32 {t2}, {tbl_a}, {sym}")             #  back to its register once it is complete: posslot_writeback)
+        e("v_readlane_b32 {t3}, {tbl_b}, {sym}")
         e("s_mov_b32 {t4}, 0")
-        e("s_add_u32 " + JPAIR_LO + ", {jb_lo}, {t5}")
+        e("s_add_u32 " + JPAIR_LO + ", {jb_lo}, {t3}")
         e("s_addc_u32 " + JPAIR_HI + ", {jb_hi}, 0")
+        for name in ("direct_chain", "dist_small", "dist_rev"):   # the computed jump's targets arrive with what is queued here
+            self.lstate[name] = self._st()
         e("s_setpc_b64 " + JPAIR)
         lab("direct_chain")
         for _ in range(26):
             self.direct_bit(R("t4"))
         lab("direct_done")
         self.tree_walk(R("m_align"), 4, first_lane="1")
+        self.posslot_writeback()
         self.tree_update(R("m_align"), 4)
         e("s_lshl_b32 {t4}, {t4}, 4")
         e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
@@ -776,11 +940,13 @@ class Gen:
         e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
         with self.in_cold():                                 # falls through into `copy`
             lab("dist_small")
+            self.posslot_writeback()
             e("s_mov_b32 {rep0}, {t2}")
             e("s_branch " + L("copy"))
             # slots 4..11: pos_decoders[result - slot + node] in m_posdec_a, ndb = 1..4 bits;
             # slots 12, 13: m_posdec_b lanes (slot - 12) * 32 + node, 5 bits
             lab("dist_rev")
+            self.posslot_writeback()
             e("s_xor_b32 {t0}, {sym}, 0x7f")                    # pos_slot
             e("s_lshr_b32 {t1}, {t0}, 1")
             e("s_add_u32 {t1}, {t1}, -1")                       # num_direct_bits;  t2 = (2 | (slot & 1)) << ndb (table)
@@ -819,8 +985,8 @@ class Gen:
         e("v_add_u32 {VLANE128}, 0x80, {v_lane}")
         e("v_add_u32 {VLANE192}, 0xc0, {v_lane}")
         e("v_cndmask_b32 {VOOB}, -1, 0, vcc")          # lane 0: 0, others: 0xFFFFFFFF (out of range)
-        e("s_movk_i32 {c2017}, 2017")
-        e("s_movk_i32 {c2048}, 0x800")
+        e("v_mov_b32 {c2017}, 2017")
+        e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
         self.set_guards(R("n0"))
         self.tables_prologue()
@@ -851,25 +1017,14 @@ class Gen:
         e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
         e("s_max_i32 {state}, {state}, 0")
         self.tree_walk(R("u0"), 6, first_lane="1")  # nodes 1..63 -> u0
-        self.tree_update(R("u0"), 6)
+        self.tree_update(R("u0"), 6, defer=True)   # (queued: emitted in the shadows of levels 6 and 7)
+        self.literal_tail(False)
         with self.in_cold():    # the same walk entered at level 1..5 by a matched literal after its first mismatch:
             for i in range(1, 6):   # only the levels from pl0 on were walked in u0
                 lab("plain%d" % i)
                 self.bit_nu(R("u0"), R("sym"))
             self.tree_update(R("u0"), 6, min_level=R("pl0"))
-            e("s_branch " + L("plain6"))
-        lab("plain6")               # nodes 64..127 -> u1 (v_readlane uses the low 6 bits of the lane select)
-        self.bit(R("u1"), R("sym"), cmp_lane=V["VLANE64"])
-        lab("plain7")               # nodes 128..191 -> u2, 192..255 -> u3
-        e("s_bitcmp1_b32 {sym}, 6")          # (set for a byte with bit 7 clear: the fall-through serves ASCII)
-        e("s_cbranch_scc0 " + L("plain7_lo"))
-        self.bit(R("u3"), R("sym"), cmp_lane=V["VLANE192"])
-        lab("lit_done")
-        self.literal_epilogue()
-        with self.in_cold():
-            lab("plain7_lo")
-            self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"])
-            self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
+            self.literal_tail(True)   # (its own copy of levels 6 / 7: entered at plain6 / plain7 with nothing queued)
 
         # Section order: a new match falls through its distance tail into `copy`, and `copy` into the top after a match, so that
         # the only taken branches of a match are the computed jump into the direct bits and the loop's back edge.
