@@ -96,37 +96,37 @@ __global__ __launch_bounds__(64, 8) void chain(uint64_t* out, uint32_t seed) {
     else if constexpr (VAR == kB6) {  // six decisions = one 6-level walk, the reference for kSpec6 (REP8 -> 48 decisions per iteration)
       asm volatile(REP8(D_HEAD D_TAIL D_HEAD D_TAIL D_HEAD D_TAIL D_HEAD D_TAIL D_HEAD D_TAIL D_HEAD D_TAIL) OPS);
     } else if constexpr (VAR == kSpec6) {
-      // v200 range, v[202:203] = (look-ahead, code) pair for v_lshlrev_b64, v204..: temporaries; s[84:85] alive mask, s[80:81] this
+      // v40 range, v[42:43] = (look-ahead, code) pair for v_lshlrev_b64, v44..: temporaries; s[84:85] alive mask, s[80:81] this
       // level's "my path takes the 1 branch" mask (constant per level in the real thing), s69 = 2^24
 #define LVL                                              \
-  "v_lshrrev_b32 v204, 11, v200\n\t"                     \
-  "v_mul_u32_u24 v205, v204, %[p]\n\t"                   \
-  "v_sub_u32 v206, v200, v205\n\t"                       \
-  "v_cndmask_b32_e64 v207, 0, v205, s[90:91]\n\t"        \
-  "v_cndmask_b32_e64 v200, v205, v206, s[90:91]\n\t"     \
-  "v_sub_u32 v203, v203, v207\n\t"                       \
-  "v_cmp_lt_u32_e64 s[84:85], v203, v200\n\t"            \
-  "v_or_b32 v200, 0x40000000, v200\n\t"                  \
-  "v_cmp_gt_u32 vcc, s69, v200\n\t"                      \
+  "v_lshrrev_b32 v44, 11, v40\n\t"                     \
+  "v_mul_u32_u24 v45, v44, %[p]\n\t"                   \
+  "v_sub_u32 v46, v40, v45\n\t"                       \
+  "v_cndmask_b32_e64 v47, 0, v45, s[90:91]\n\t"        \
+  "v_cndmask_b32_e64 v40, v45, v46, s[90:91]\n\t"     \
+  "v_sub_u32 v43, v43, v47\n\t"                       \
+  "v_cmp_lt_u32_e64 s[84:85], v43, v40\n\t"            \
+  "v_or_b32 v40, 0x40000000, v40\n\t"                  \
+  "v_cmp_gt_u32 vcc, s69, v40\n\t"                      \
   "s_nop 1\n\t"                                          \
-  "v_cndmask_b32_e64 v208, 0, 8, vcc\n\t"                \
-  "v_lshlrev_b32 v200, v208, v200\n\t"                   \
-  "v_lshlrev_b64 v[202:203], v208, v[202:203]\n\t"
+  "v_cndmask_b32_e64 v48, 0, 8, vcc\n\t"                \
+  "v_lshlrev_b32 v40, v48, v40\n\t"                   \
+  "v_lshlrev_b64 v[42:43], v48, v[42:43]\n\t"
       asm volatile(REP8(
-          "v_mov_b32 v200, s66\n\t"
-          "v_mov_b32 v203, s67\n\t"
-          "v_mov_b32 v202, s68\n\t"
+          "v_mov_b32 v40, s66\n\t"
+          "v_mov_b32 v43, s67\n\t"
+          "v_mov_b32 v42, s68\n\t"
           LVL LVL LVL LVL LVL LVL
           "s_or_b64 s[84:85], s[84:85], 0x20\n\t"       // (dummy data: make sure one lane "survives")
           "s_ff1_i32_b64 s86, s[84:85]\n\t"
           "s_nop 3\n\t"
-          "v_readlane_b32 s66, v200, s86\n\t"
-          "v_readlane_b32 s67, v203, s86\n\t"
-          "v_readlane_b32 s68, v202, s86\n\t"
+          "v_readlane_b32 s66, v40, s86\n\t"
+          "v_readlane_b32 s67, v43, s86\n\t"
+          "v_readlane_b32 s68, v42, s86\n\t"
           "s_or_b32 s66, s66, 0x40000000\n\t")
           :
           : [p] "v"(prob)
-          : "s66", "s67", "s68", "s84", "s85", "s86", "scc", "vcc", "v200", "v202", "v203", "v204", "v205", "v206", "v207", "v208");
+          : "s66", "s67", "s68", "s84", "s85", "s86", "scc", "vcc", "v40", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
     } else if constexpr (VAR == kV3chain || VAR == kV3idx || VAR == kV3half) {
       asm volatile(REP8("v_lshrrev_b32 %[vt], 11, %[vr]\n\t"
                         "v_mul_u32_u24 %[vb], %[vt], %[p]\n\t"
