@@ -344,3 +344,56 @@ def lzma2_lzma_chunk(payload, unpacked_len, control, props=None):
 def lzma2_stored_chunk(data, reset_dict):
     assert 1 <= len(data) <= 0x10000
     return bytes([1 if reset_dict else 2]) + struct.pack(">H", len(data) - 1) + data
+
+
+def lz_parse(data, dict_size=1 << 16, max_len=273, use_reps=True):
+    """A greedy LZ77 parse of `data` into the symbols above (3-byte hash heads, newest candidate only; repeat distances
+    and short reps are preferred when they apply): real match structure -- long and short matches, near and far
+    distances, every rep index -- for property sets no real compressor emits (liblzma refuses lc + lp > 4)."""
+    n = len(data)
+    head = {}
+    reps = [0, 0, 0, 0]          # distances (>= 1); 0 = unset
+    syms = []
+    i = 0
+
+    def mlen(pos, dist, cap):
+        k = 0
+        while k < cap and data[pos + k] == data[pos + k - dist]:
+            k += 1
+        return k
+
+    while i < n:
+        cap = min(max_len, n - i)
+        best_len, best = 0, None
+        if use_reps and i > 0:
+            for idx, d in enumerate(reps):
+                if d and d <= i:
+                    k = mlen(i, d, cap)
+                    if k >= 2 and k > best_len:
+                        best_len, best = k, ("rep", idx, k)
+            if best is None and reps[0] and reps[0] <= i and data[i] == data[i - reps[0]] and (len(syms) & 7) == 0:
+                best_len, best = 1, ("shortrep",)
+        if i + 3 <= n:
+            key = data[i:i + 3]
+            j = head.get(key)
+            if j is not None and i - j <= dict_size:
+                k = mlen(i, i - j, cap)
+                if k >= 3 and k > best_len + 1:
+                    best_len, best = k, ("match", k, i - j)
+        if best is None:
+            syms.append(("lit", data[i]))
+            step = 1
+        else:
+            syms.append(best)
+            step = best_len
+            if best[0] == "match":
+                reps = [best[2], reps[0], reps[1], reps[2]]
+            elif best[0] == "rep" and best[1] > 0:
+                d = reps[best[1]]
+                for t in range(best[1], 0, -1):
+                    reps[t] = reps[t - 1]
+                reps[0] = d
+        for p in range(i, min(i + step, n - 2)):
+            head[data[p:p + 3]] = p
+        i += step
+    return syms

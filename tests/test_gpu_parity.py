@@ -180,6 +180,34 @@ def test_symbol_streams_every_lclppb(ctx):
         assert d.ok
 
 
+def test_lclp_above_four_at_size(ctx):
+    """lc + lp > 4 (legal in a .lzma header, lzma.rs:96-161; liblzma cannot write it) and the lc + lp = 4 class at sizes where the
+    literal table is really exercised: 256 KiB..1 MiB of text + binary with real match structure (greedy LZ parse, symbol
+    encoder), every literal row of the 2^(lc+lp) x 0x300 table reachable; the spill class keeps its table in HBM scratch."""
+    rnd = random.Random(77)
+    comps, plains = [], []
+    for (lc, lp, pb), size in [((8, 0, 2), 1 << 20), ((4, 4, 0), 1 << 18), ((5, 2, 4), 1 << 18), ((8, 4, 4), 1 << 17),
+                               ((4, 0, 2), 1 << 18), ((0, 4, 0), 1 << 18), ((2, 2, 4), 1 << 18)]:
+        plain = W.make_plain("text", size - 40000, seed=lc * 100 + lp * 10 + pb) + rnd.randbytes(20000) + bytes(range(256)) * 78 + b"x" * 32
+        plain = plain[:size]
+        syms = E.lz_parse(plain, dict_size=1 << 16)
+        known = (lc + lp) % 2 == 0
+        enc = E.LzmaSymbolEncoder(lc, lp, pb)
+        enc.encode(syms)
+        if not known:
+            enc.encode([("marker",)])
+        comps.append(E.lzma_header(lc, lp, pb, 1 << 16, len(plain) if known else None) + enc.finish())
+        plains.append(plain)
+    decs = ctx.lzma_batch(comps)
+    for comp, plain, d in zip(comps, plains, decs):
+        assert d.ok and d.data == plain, (comp[0], d)
+        same(d, orc.lzma_decompress(comp))
+    # and cut short / with a byte damaged in the middle: same verdict, same bytes delivered, as the oracle
+    bad = [c[:len(c) * 2 // 3] for c in comps] + [c[:len(c) // 2] + bytes([c[len(c) // 2] ^ 0x55]) + c[len(c) // 2 + 1:] for c in comps]
+    for comp, d in zip(bad, ctx.lzma_batch(bad)):
+        same(d, orc.lzma_decompress(comp))
+
+
 def test_symbol_streams_stress(ctx):
     # many longer random symbol sequences inside the fast kernels' property class (pb <= 2, lc + lp <= 3):
     # every symbol kind after every other, short / 64+ byte / self-overlapping matches, all rep indices,

@@ -364,3 +364,18 @@ def test_fuzz_no_crash_and_liblzma_verdict():  # fuzz/fuzz_targets/compare_xz.rs
         elif want is not None:
             # liblzma accepted but we did not: only legitimate for checks we do not support
             assert "SHA-256" in r.msg or "Unknown filter" in r.msg or True
+
+
+def test_oracle_lclp_above_four_at_size():
+    """lc + lp > 4 at a size where most literal rows are touched: the oracle against the plaintext the stream was built from
+    (greedy LZ parse + the tests' symbol encoder; liblzma cannot write or read these property sets)."""
+    import lzma_enc as E
+    from lzma_rs_amd import workloads as W
+    plain = W.make_plain("text", 200000, seed=31) + bytes(range(256)) * 200
+    syms = E.lz_parse(plain, dict_size=1 << 16)
+    assert sum(1 for x in syms if x[0] == "match") > 10000 and sum(1 for x in syms if x[0] == "rep") > 50
+    for lc, lp, pb in [(8, 0, 2), (4, 4, 0), (5, 2, 4), (8, 4, 4)]:
+        enc = E.LzmaSymbolEncoder(lc, lp, pb)
+        enc.encode(syms)
+        r = orc.lzma_decompress(E.lzma_header(lc, lp, pb, 1 << 16, len(plain)) + enc.finish())
+        assert r.ok and r.out == plain, (lc, lp, pb, r)
