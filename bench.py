@@ -151,8 +151,9 @@ def build_batch(n_items, size, kind, dict_size, first_index, processes, mode="lz
     import lzma_rs_amd as M
     t0 = time.time()
     comps, crcs = compress_items(mode, n_items, size, kind, dict_size, first_index, processes)
-    units_l, blobs, in_off, out_off, comp_total = [], [], 0, 0, 0
+    units_l, blobs, in_off, out_off, comp_total, starts = [], [], 0, 0, 0, []
     for comp in comps:
+        starts.append(in_off)
         if mode == "xz":
             us, _ = M.xz_plan(comp)
             for u in us:
@@ -177,6 +178,7 @@ def build_batch(n_items, size, kind, dict_size, first_index, processes, mode="lz
         in_off += len(payload) + pad
     units = (M.Unit * len(units_l))(*units_l)
     build_batch.crcs = [c for per in crcs for c in per]
+    build_batch.starts = starts + [in_off]
     return units, b"".join(blobs), comp_total, time.time() - t0
 
 
@@ -268,6 +270,31 @@ def verify_units(M, ctx, units, res, d_out, stream, crcs_d, n, upi, distinct, si
     return bad, verified
 
 
+def cut_pool_for_ranks(M, D, pool_units, pool_blob, pool_crcs, starts, n_items, upi, size, world):
+    """Rank 0 as the node's ingest point: the pool's items (streams / .xz files) partitioned over the ranks by compressed
+    bytes with the library's planner (milzma_partition via D.shard_by_bytes; the blocks of a file stay together because the
+    item is the file).  Returns per rank (blob bytes, units ctypes array with offsets relative to that blob / to output
+    offset 0, crcs)."""
+    sizes = [starts[i + 1] - starts[i] for i in range(n_items)]
+    shares = D.shard_by_bytes(sizes, world)
+    out = []
+    for share in shares:
+        blob, units, crcs, pos = [], [], [], 0
+        for k, i in enumerate(share):
+            blob.append(pool_blob[starts[i]:starts[i + 1]])
+            for j in range(upi):
+                src = pool_units[i * upi + j]
+                u = M.Unit()
+                ctypes.memmove(ctypes.byref(u), ctypes.byref(src), ctypes.sizeof(M.Unit))
+                u.in_off = src.in_off - starts[i] + pos
+                u.out_off = src.out_off - i * size + k * size
+                units.append(u)
+                crcs.append(pool_crcs[i * upi + j])
+            pos += starts[i + 1] - starts[i]
+        out.append((b"".join(blob), (M.Unit * len(units))(*units), crcs))
+    return out
+
+
 def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
     """One of the other single-GPU BASELINE configs, measured exactly like the headline (device-resident input and output,
     K timed steps of milzma_decode_units, every unit CRC-verified afterwards); returned as a dict for `other_configs`."""
@@ -312,6 +339,110 @@ def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg}}
 
 
+def run_inproc(args):
+    """--gpus N --inproc: the N GPUs of the node from ONE process through the library's own multi-device entry point
+    (milzma_multi_decode_units: one context + one host thread per device inside libmilzma.so, no torch.distributed, no
+    collective).  Device d decodes its own 4096 streams (seed indices d * n ...), inputs and outputs resident in that
+    device's HBM; a step = one call over all devices; verification = GPU CRC-32 of every unit on every device."""
+    import torch
+    import lzma_rs_amd as M
+    global PROPS
+    PROPS = tuple(int(x) for x in args.props.split(","))
+    cfg = CONFIGS[args.config]
+    mode = "xz" if args.config == "xz" else "lzma"
+    n, size, dict_size = args.streams or cfg["streams"], args.size or cfg["size"], args.dict or cfg["dict"]
+    nd = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < nd:
+        raise SystemExit("bench.py --gpus %d --inproc: this node exposes %d GPU(s); refusing to label a smaller run as %d GPUs"
+                         % (nd, have, nd))
+    distinct = n if args.distinct == 0 else min(n, cfg["distinct"] if args.distinct < 0 else args.distinct)
+    cores = effective_cores()
+    per_dev, gen_s = [], 0.0
+    for d in range(nd):
+        units_d, blob_d, _, g = build_batch(distinct, size, args.kind, dict_size, d * n, cores, mode)
+        gen_s += g
+        per_dev.append((units_d, blob_d, list(build_batch.crcs)))
+    cpu_line = None
+    if nd == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(1 << 20 if mode == "xz" else size, args.kind, dict_size, cores)
+    m = M.MultiContext((1 << nd) - 1)
+    upi = len(per_dev[0][0]) // distinct
+    all_units, device_of, d_ins, d_outs, comp_total = [], [], [], [], 0
+    for d, (units_d, blob_d, _) in enumerate(per_dev):
+        units, comp = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
+        comp_total += comp
+        reps = (n + distinct - 1) // distinct
+        h = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
+        dev = torch.device("cuda", d)
+        d_ins.append((h.repeat(reps) if reps > 1 else h).to(dev))
+        d_outs.append(torch.empty(n * size + 512, dtype=torch.uint8, device=dev))
+        all_units.extend(units)
+        device_of.extend([d] * len(units))
+    arr = (M.Unit * len(all_units))(*all_units)
+    pin, pout = [t.data_ptr() for t in d_ins], [t.data_ptr() for t in d_outs]
+
+    def sync():
+        for d in range(nd):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        m.decode_units(arr, device_of, pin, pout)
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = m.decode_units(arr, device_of, pin, pout)
+        kernel_ms.append(m.kernel_ms()[0])
+    sync()
+    elapsed = time.perf_counter() - t0
+    bad = verified = 0
+    if not args.no_verify:
+        for t in d_outs:
+            t.zero_()
+        res = m.decode_units(arr, device_of, pin, pout)
+        per = n * upi
+        for d in range(nd):
+            c = M.Context(d)
+            sub = (M.Unit * per)(*all_units[d * per:(d + 1) * per])
+            subres = (M.Result * per)(*[res[d * per + i] for i in range(per)])
+            torch.cuda.set_device(d)
+            b, v = verify_units(M, c, sub, subres, d_outs[d], 0, per_dev[d][2], n, upi, distinct, size, mode)
+            bad += b
+            verified += v
+            c.close()
+    else:
+        bad = sum(1 for r in res if r.status != M.ST_OK)
+    step_s = elapsed / args.steps
+    total_out = n * size * nd
+    k_ms = statistics.median(kernel_ms)
+    alg = (comp_total + total_out) // nd
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    what = ("%d .xz files of %d B per GPU: %d LZMA2 units" % (n, size, n * upi) if mode == "xz"
+            else "%d independent %d-byte .lzma streams per GPU" % (n, size))
+    line = {"metric": "decompressed GB/s (whole node), %d x %d B LZMA %s per GPU" % (n, size, "files" if mode == "xz" else "streams"),
+            "value": round(total_out / step_s / 1e9, 4), "unit": "GB/s", "n_gpus": nd, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic", "streams_per_s": round(n * nd / step_s, 1), "bit_exact": bad == 0,
+            "config": {"workload": "configs[%d]: %s, lc%d/lp%d/pb%d, dict %d, class %s, liblzma preset 6, known-size headers"
+                                   % ((cfg["idx"], what) + PROPS + (dict_size, args.kind)),
+                       "streams_per_gpu": n, "units_per_gpu": n * upi, "distinct_streams_per_gpu": distinct, "stream_bytes": size,
+                       "dict_size": dict_size, "class": args.kind, "generation_s": round(gen_s, 1),
+                       "verified_streams_per_gpu": verified // upi // nd,
+                       "parallelism": "in-process: milzma_multi_decode_units, one context + host thread per device, devices %s, "
+                                      "%d streams per GPU, no collective" % (m.devices, n)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "traffic_note": "per GPU; see the one-process-per-GPU line for the PMC-backed figure",
+                         "kernel": "decode kernel(s) of one device's share (slowest device)", "kernel_ms": round(k_ms, 3),
+                         "kernel_source_sha256": kernel_source_hash(), "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu_line}
+    print(json.dumps(line))
+    m.close()
+    if bad:
+        raise SystemExit("bench: %d units failed verification" % bad)
+
+
 # ---- launching -----------------------------------------------------------------------------------------
 def self_launch(n_gpus):
     """--gpus N outside torchrun: one rank per GPU of this node, or a loud failure"""
@@ -354,9 +485,14 @@ def main():
                     help="comma list of further single-GPU BASELINE configs measured after the headline and attached as "
                          "`other_configs` (auto = dict8m,xz on a default 1-GPU headline run; none = skip)")
     ap.add_argument("--other-steps", type=int, default=3)
+    ap.add_argument("--inproc", action="store_true",
+                    help="the N GPUs from ONE process through milzma_multi_decode_units (the library's own multi-device entry "
+                         "point: a host thread per device) instead of one rank per GPU over torch.distributed")
     ap.add_argument("--dry-run", action="store_true", help="everything up to (not including) the first decode: no GPU needed")
     args = ap.parse_args()
 
+    if args.inproc:
+        return run_inproc(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
 
@@ -378,12 +514,22 @@ def main():
     procs = max(1, cores // world)
     distinct = n if args.distinct == 0 else min(n, cfg["distinct"] if args.distinct < 0 else args.distinct)
     # host-side generation first (forks worker processes): before any HIP/RCCL state exists
-    # (--scatter: rank 0 is the node's ingest point and holds every rank's input; to keep host generation at one batch
-    #  the ranks then all decode the same streams, and each builds its descriptors from its own identical copy)
-    first = 0 if args.scatter else rank * n
-    units_d, blob_d, comp_d, gen_s = build_batch(distinct, size, args.kind, dict_size, first, procs, mode)
-    crcs_d = build_batch.crcs
-    upi = len(units_d) // distinct  # units per item (4 blocks per .xz file)
+    scatter = args.scatter and world > 1
+    shares = None
+    if scatter:
+        # north_star: "RCCL ... only for input scatter and output gather".  Rank 0 is the node's ingest point: it holds a pool of
+        # world x `distinct` DIFFERENT streams, partitions them over the ranks by compressed bytes and ships every rank its share.
+        units_d, blob_d, comp_d, gen_s, crcs_d = None, b"", 0, 0.0, []
+        upi = 4 if mode == "xz" else 1
+        if rank == 0:
+            pool_units, pool_blob, _, gen_s = build_batch(distinct * world, size, args.kind, dict_size, 0, cores, mode)
+            upi = len(pool_units) // (distinct * world)
+            shares = cut_pool_for_ranks(M, D, pool_units, pool_blob, build_batch.crcs, build_batch.starts, distinct * world, upi,
+                                        size, world)
+    else:
+        units_d, blob_d, comp_d, gen_s = build_batch(distinct, size, args.kind, dict_size, rank * n, procs, mode)
+        crcs_d = build_batch.crcs
+        upi = len(units_d) // distinct  # units per item (4 blocks per .xz file)
     cpu_line = None
     if world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu_line = cpu_baseline(1 << 20 if mode == "xz" else size, args.kind, dict_size, cores)
@@ -391,22 +537,47 @@ def main():
     if not args.dry_run and torch.cuda.is_available() and torch.cuda.device_count() > 0:
         torch.cuda.set_device(local_rank % torch.cuda.device_count())  # before the process group exists: RCCL binds to it
     D.init()
+    use_gpu = not args.dry_run
+    scatter_s = 0.0
+    if scatter:
+        import pickle
+        sdev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count())) if use_gpu else torch.device("cpu")
+        D.barrier_sync(sdev if use_gpu else None)
+        t0 = time.perf_counter()
+        blobs = [torch.frombuffer(bytearray(b), dtype=torch.uint8) for b, _, _ in shares] if rank == 0 else None
+        d_blob = D.scatter_inputs(blobs, sdev)               # the compressed payloads, device to device (RCCL / xGMI on GPUs)
+        if use_gpu:
+            torch.cuda.synchronize(sdev)
+        D.barrier_sync(sdev if use_gpu else None)
+        scatter_s = D.max_over_ranks(time.perf_counter() - t0, sdev if use_gpu else None)
+        metas = ([torch.frombuffer(bytearray(pickle.dumps((bytes(u), c, upi))), dtype=torch.uint8) for _, u, c in shares]
+                 if rank == 0 else None)
+        meta = pickle.loads(D.scatter_inputs(metas, sdev).cpu().numpy().tobytes())   # descriptors + expected CRCs (small)
+        upi = meta[2]
+        units_d = (M.Unit * (len(meta[0]) // ctypes.sizeof(M.Unit))).from_buffer_copy(meta[0])
+        crcs_d = meta[1]
+        distinct = len(units_d) // upi
+        blob_len = int(d_blob.numel())
+    else:
+        blob_len = len(blob_d)
     n_units = n * upi
     reps = (n + distinct - 1) // distinct
-    units, comp_total = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
+    units, comp_total = tile_units(M, units_d, blob_len, n, distinct, upi, size)
     out_bytes_rank = n * size
-    h_in_one = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
-    h_in = h_in_one.repeat(reps) if reps > 1 else h_in_one
+    if not scatter:
+        h_in_one = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
+        h_in = h_in_one.repeat(reps) if reps > 1 else h_in_one
 
     if args.dry_run:  # the rank logic without a GPU (tests/test_distributed_cpu.py, gloo)
-        if args.scatter and world > 1:
-            mine = D.scatter_inputs([h_in for _ in range(world)] if rank == 0 else None, torch.device("cpu"))
-            assert mine.numel() == h_in.numel()
+        if scatter:
+            assert d_blob.numel() == blob_len and len(crcs_d) == distinct * upi
         D.barrier_sync(None)
         t = D.max_over_ranks(0.001 * (rank + 1), None)
         total_units = int(D.sum_over_ranks(n_units, None))
+        total_distinct = int(D.sum_over_ranks(distinct, None))
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "units_all_ranks": total_units, "max_time": t,
+                              "distinct_all_ranks": total_distinct,
                               "config": {"workload": "configs[%d]" % cfg["idx"], "units_per_gpu": n_units}}))
         return
 
@@ -419,14 +590,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     ctx = M.Context(dev_index)
     scatter_line = None
-    if args.scatter and world > 1:
-        # north_star: "RCCL ... only for input scatter and output gather".  Rank 0 plays the node's ingest point.
-        D.barrier_sync(dev)
-        t0 = time.perf_counter()
-        d_in = D.scatter_inputs([h_in for _ in range(world)] if rank == 0 else None, dev)
-        torch.cuda.synchronize(dev)
-        D.barrier_sync(dev)
-        scatter_s = D.max_over_ranks(time.perf_counter() - t0, dev)
+    if scatter:
+        d_in = d_blob.repeat(reps) if reps > 1 else d_blob       # every slot reads its own copy, tiled on the device
+        d_in = torch.cat([d_in, torch.zeros(512, dtype=torch.uint8, device=dev)])
     else:
         d_in = h_in.to(dev)
     d_out = torch.empty(out_bytes_rank + 512, dtype=torch.uint8, device=dev)
@@ -458,26 +624,43 @@ def main():
         bad = sum(1 for r in res if r.status != M.ST_OK)
     bad_total = int(D.sum_over_ranks(bad, dev))
 
-    if args.scatter and world > 1:
+    if scatter:
         D.barrier_sync(dev)
         t0 = time.perf_counter()
         outs = D.gather_outputs(d_out[:out_bytes_rank], dev)
         torch.cuda.synchronize(dev)
         D.barrier_sync(dev)
         gather_s = D.max_over_ranks(time.perf_counter() - t0, dev)
-        gathered_ok = None
-        if rank == 0:  # what arrived is what the ranks decoded (rank r's batch tiles the same distinct items here only
-            gathered_ok = all(o.numel() == out_bytes_rank for o in outs)  # if first_index coincides: lengths are checked)
+        gathered_bad = None
+        if rank == 0:   # what arrived at the ingest point is what the ranks decoded: GPU CRC-32 of every gathered unit
+            gathered_bad = 0
+            for r, o in enumerate(outs):
+                _, u_r, c_r = shares[r]
+                d_r = len(u_r) // upi
+                tiled, _ = tile_units(M, u_r, 0, n, d_r, upi, size)
+                fake = (M.Result * len(tiled))()
+                for i in range(len(tiled)):
+                    fake[i].out_len = tiled[i].out_cap if mode == "xz" else size
+                if o.numel() != out_bytes_rank:
+                    gathered_bad += len(tiled)
+                    continue
+                o = torch.cat([o, torch.zeros(512, dtype=torch.uint8, device=dev)])
+                b, _ = verify_units(M, ctx, tiled, fake, o, stream, c_r, n, upi, d_r, size, mode)
+                gathered_bad += b
         scatter_line = {"scatter_s": round(scatter_s, 4), "gather_s": round(gather_s, 4),
-                        "scatter_GBps": round(h_in.numel() * (world - 1) / scatter_s / 1e9, 2),
+                        "scatter_GBps": round(comp_total / max(1, reps) * (world - 1) / max(scatter_s, 1e-9) / 1e9, 2),
                         "gather_GBps": round(out_bytes_rank * (world - 1) / gather_s / 1e9, 2),
-                        "gathered_lengths_ok": gathered_ok,
-                        "note": "rank 0 -> every rank (compressed), every rank -> rank 0 (decoded), point-to-point over the "
-                                "process group (RCCL / xGMI on GPUs); not part of `value`"}
+                        "gathered_units_bad": gathered_bad,
+                        "note": "rank 0 holds a pool of world x distinct different streams, partitions it by compressed bytes "
+                                "(milzma_partition) and sends every rank its share; every rank returns its decoded output; "
+                                "point-to-point over the process group (RCCL / xGMI on GPUs); rank 0 CRC-checks every gathered "
+                                "unit on its GPU; not part of `value`"}
+        if rank == 0 and gathered_bad:
+            bad_total += gathered_bad
         del outs
 
     pcie = None
-    if args.pcie:
+    if args.pcie and not scatter:
         pcie = pcie_inclusive(ctx, M, torch, dev, units, h_in, d_in, d_out, n_units, out_bytes_rank)
 
     others = {}

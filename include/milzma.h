@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MILZMA_ABI_VERSION 1
+#define MILZMA_ABI_VERSION 2
 
 /* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
 enum {
@@ -211,6 +211,56 @@ int milzma_xz_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const
  * is not OK gets 0. */
 int milzma_crc_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_out,
                      const milzma_result *results, uint32_t *crc32, uint64_t *crc64, void *hip_stream);
+
+/* ---- several GPUs of one node behind one handle --------------------------------------------------
+ * Every public entry point of the reference builds a fresh decoder (src/lib.rs:44-105, src/decode/lzma2.rs:23-34):
+ * streams, LZMA2 groups and XZ blocks are independent, so a batch shards across devices with no exchange between
+ * them.  A milzma_multi owns one milzma_ctx and one host worker thread per device; the work of a call is
+ * partitioned by compressed bytes (what a wavefront's time follows), each device's share travels over that
+ * device's own PCIe link, is decoded there and comes back the same way, all devices concurrently.  Nothing is
+ * funnelled through one GPU (no xGMI hop is needed for host-resident data); callers whose data already lives
+ * in the devices' memory use milzma_multi_decode_units. */
+typedef struct milzma_multi milzma_multi;
+
+/* device_mask: bit d = HIP ordinal d; 0 = every visible device.  Fails (MILZMA_INFRA_ERROR, text from
+ * milzma_multi_last_error(NULL)) if a named device is missing or is not a gfx950: no partial sets, no CPU fallback. */
+int milzma_multi_create(uint64_t device_mask, milzma_multi **out);
+void milzma_multi_destroy(milzma_multi *m);
+/* number of devices; their HIP ordinals into ordinals[0..cap) when not NULL */
+uint32_t milzma_multi_devices(const milzma_multi *m, int *ordinals, uint32_t cap);
+const char *milzma_multi_last_error(const milzma_multi *m);
+/* kernel ms / launches of device index k's share of the most recent call (max over devices when k == UINT32_MAX) */
+float milzma_multi_last_kernel_ms(const milzma_multi *m, uint32_t k, uint32_t *launches);
+
+/* The partition the multi entry points use; needs no GPU.  Item i (a unit, or a whole file) has weight weights[i]
+ * (compressed bytes) and goes to part part_of[i] in [0, parts).  Longest-processing-time-first: items by falling
+ * weight, each to the lightest part so far (ties: lowest part index; equal weights: lowest item index first), which
+ * keeps the heaviest part within one item of the mean.  group (may be NULL): items with the same non-zero group id
+ * stay together (the LZMA2 units of one stream, the blocks of one .xz file) and are placed as one item of their
+ * summed weight.  Deterministic. */
+int milzma_partition(const uint64_t *weights, const uint32_t *group, uint32_t n, uint32_t parts,
+                     uint32_t *part_of);
+
+/* milzma_decode_units_host over all devices of m: same arguments, same checks, same results. */
+int milzma_multi_decode_units_host(milzma_multi *m, const milzma_unit *units, uint32_t n,
+                                   const void *h_in, size_t in_bytes, void *h_out, size_t out_bytes,
+                                   milzma_result *results);
+/* milzma_decode_units for data that already lives on the devices: unit i runs on device index device_of[i] (an
+ * index into the handle's device list) and addresses d_in[device_of[i]] / d_out[device_of[i]] (device pointers on
+ * that device; slack rules as for milzma_decode_units).  One launch sequence per device, all devices concurrently;
+ * returns when every device's results are back. */
+int milzma_multi_decode_units(milzma_multi *m, const milzma_unit *units, uint32_t n,
+                              const uint32_t *device_of, const void *const *d_in, void *const *d_out,
+                              milzma_result *results);
+/* The whole-file batch entry points over all devices: files are partitioned by size, outs[i] is exactly what the
+ * single-device call (and the reference) produces for file i. */
+int milzma_multi_lzma_decompress_batch(milzma_multi *m, uint32_t n, const uint8_t *const *ins,
+                                       const size_t *in_lens, const milzma_options *opt,
+                                       milzma_output *outs);
+int milzma_multi_lzma2_decompress_batch(milzma_multi *m, uint32_t n, const uint8_t *const *ins,
+                                        const size_t *in_lens, milzma_output *outs);
+int milzma_multi_xz_decompress_batch(milzma_multi *m, uint32_t n, const uint8_t *const *ins,
+                                     const size_t *in_lens, milzma_output *outs);
 
 /* ---- host-side parsing, usable without a GPU (and tested without one) -------------------- */
 

@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_float, c_int, c_void};
 
-pub const MILZMA_ABI_VERSION: u32 = 1;
+pub const MILZMA_ABI_VERSION: u32 = 2;
 
 // error kinds: error::Error variants (src/error.rs:8-17)
 pub const MILZMA_OK: c_int = 0;
@@ -81,6 +81,12 @@ pub struct milzma_output {
 
 #[repr(C)]
 pub struct milzma_ctx {
+    _opaque: [u8; 0],
+}
+
+/// Several GPUs of one node behind one handle (one context + one host worker thread per device).
+#[repr(C)]
+pub struct milzma_multi {
     _opaque: [u8; 0],
 }
 
@@ -184,4 +190,53 @@ extern "C" {
     ) -> c_int;
     pub fn milzma_crc32(p: *const u8, n: usize) -> u32;
     pub fn milzma_crc64(p: *const u8, n: usize) -> u64;
+
+    // ---- several GPUs of one node ------------------------------------------------------------------
+    pub fn milzma_multi_create(device_mask: u64, out: *mut *mut milzma_multi) -> c_int;
+    pub fn milzma_multi_destroy(m: *mut milzma_multi);
+    pub fn milzma_multi_devices(m: *const milzma_multi, ordinals: *mut c_int, cap: u32) -> u32;
+    pub fn milzma_multi_last_error(m: *const milzma_multi) -> *const c_char;
+    pub fn milzma_multi_last_kernel_ms(m: *const milzma_multi, k: u32, launches: *mut u32) -> c_float;
+    pub fn milzma_partition(weights: *const u64, group: *const u32, n: u32, parts: u32, part_of: *mut u32) -> c_int;
+    pub fn milzma_multi_decode_units_host(
+        m: *mut milzma_multi,
+        units: *const milzma_unit,
+        n: u32,
+        h_in: *const c_void,
+        in_bytes: usize,
+        h_out: *mut c_void,
+        out_bytes: usize,
+        results: *mut milzma_result,
+    ) -> c_int;
+    pub fn milzma_multi_decode_units(
+        m: *mut milzma_multi,
+        units: *const milzma_unit,
+        n: u32,
+        device_of: *const u32,
+        d_in: *const *const c_void,
+        d_out: *const *mut c_void,
+        results: *mut milzma_result,
+    ) -> c_int;
+    pub fn milzma_multi_lzma_decompress_batch(
+        m: *mut milzma_multi,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        opt: *const milzma_options,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_multi_lzma2_decompress_batch(
+        m: *mut milzma_multi,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_multi_xz_decompress_batch(
+        m: *mut milzma_multi,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
 }

@@ -8,99 +8,42 @@
 //! pub fn xz_decompress<R, W>(input, output) -> error::Result<()>
 //! ```
 //!
+//! `error` and `decompress` ARE the crate's own modules (re-exported from the `lzma-rs` dependency): the error type a
+//! caller matches on and the options it builds are the same values whichever decoder runs.
+//!
 //! Semantics kept from the crate: on error the bytes the reference would already have written to `W` are
 //! still written (ring flushes, LZMA2 dictionary resets); the reader is left after the last byte the
 //! reference would have consumed (a known-size `.lzma` stops before trailing bytes, LZMA2 after its 0x00
 //! status byte); the Display strings of `error::Error` are the reference's.
 //!
 //! How the generic `R: BufRead` meets a batch decoder (`run`): the bytes one `fill_buf` shows are decoded WITHOUT
-//! consuming; the library reports `in_consumed`; exactly that many bytes are then `consume`d -- for a slice or a
-//! `Cursor` this is the reference's behaviour to the byte.  A reader whose `fill_buf` cannot show the whole
-//! input at once (a `BufReader` over a large file) is read to its end and decoded again; bytes past `in_consumed`
-//! cannot be given back to such a reader (`io::BufRead` has no un-read), which is the one difference from the
-//! streaming reference and only matters to callers that keep reading from the same reader after a known-size
-//! stream.  `*_batch` functions take slices and have no such caveat.
+//! consuming, and the library reports `in_consumed`.
+//! * `in_consumed` < the bytes shown: the verdict (success or error) was reached inside the view and cannot depend on
+//!   what follows it; exactly `in_consumed` bytes are consumed -- for a slice or a `Cursor` the reference's reader
+//!   position to the byte, errors included.
+//! * `in_consumed` == the bytes shown: the decoder ran to the end of the view -- which is the real end of a slice, but only
+//!   a buffer boundary of a `BufReader` over a large file (an unknown-size `.lzma` stream is "finished" when the reader is
+//!   at EOF with `code == 0`, src/decode/lzma.rs:446-455: a view cut there would be accepted short).  The view is
+//!   consumed and the reader probed with another `fill_buf`: empty = that was the end, the verdict stands; otherwise
+//!   everything is read and decoded again, and the reader is left at ITS end (`io::BufRead` has no un-read) -- the one
+//!   difference from the streaming reference, and only for readers that cannot show their input at once.
+//! `*_batch` functions take slices and have no such caveat.
 //!
-//! NOTE: written without a Rust toolchain (the build image has none); never compiled.
+//! NOTE: written without a Rust toolchain (the build image has none); never compiled.  README.md: how to build and
+//! test it where one exists.
 
 pub mod ffi;
+
+pub use lzma_rs::{decompress, error};
 
 use std::ffi::CStr;
 use std::io;
 use std::ptr;
+use std::rc::Rc;
 
-/// Error handling: src/error.rs of the crate.
-pub mod error {
-    use std::fmt::Display;
-    use std::{io, result};
-
-    /// Library errors (src/error.rs:8-17).
-    #[derive(Debug)]
-    pub enum Error {
-        /// I/O error.
-        IoError(io::Error),
-        /// Not enough bytes to complete header
-        HeaderTooShort(io::Error),
-        /// LZMA error.
-        LzmaError(String),
-        /// XZ error.
-        XzError(String),
-    }
-
-    /// Library result alias.
-    pub type Result<T> = result::Result<T, Error>;
-
-    impl From<io::Error> for Error {
-        fn from(e: io::Error) -> Error {
-            Error::IoError(e)
-        }
-    }
-
-    impl Display for Error {
-        fn fmt(&self, fmt: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
-            match self {
-                Error::IoError(e) => write!(fmt, "io error: {}", e),
-                Error::HeaderTooShort(e) => write!(fmt, "header too short: {}", e),
-                Error::LzmaError(e) => write!(fmt, "lzma error: {}", e),
-                Error::XzError(e) => write!(fmt, "xz error: {}", e),
-            }
-        }
-    }
-
-    impl std::error::Error for Error {
-        fn source(&self) -> Option<&(dyn std::error::Error + 'static)> {
-            match self {
-                Error::IoError(e) | Error::HeaderTooShort(e) => Some(e),
-                Error::LzmaError(_) | Error::XzError(_) => None,
-            }
-        }
-    }
-}
-
-/// Decompression helpers: src/decode/options.rs of the crate.
-pub mod decompress {
-    /// Options to tweak decompression behavior (src/decode/options.rs:3-20).
-    #[derive(Clone, Copy, Debug, PartialEq, Eq, Default)]
-    pub struct Options {
-        /// Whether the unpacked size is read from the header or provided.
-        pub unpacked_size: UnpackedSize,
-        /// Limit of the dictionary's dynamic size.
-        pub memlimit: Option<usize>,
-        /// Stream API only; no effect here (as in the crate's one-shot functions).
-        pub allow_incomplete: bool,
-    }
-
-    /// Alternatives for defining the unpacked size (src/decode/options.rs:22-43).
-    #[derive(Clone, Copy, Debug, PartialEq, Eq, Default)]
-    pub enum UnpackedSize {
-        /// 8 size bytes in the header; all ones = end-of-payload marker.
-        #[default]
-        ReadFromHeader,
-        /// 8 size bytes in the header, read and ignored; the provided value is used.
-        ReadHeaderButUseProvided(Option<u64>),
-        /// No size bytes in the header; the provided value is used.
-        UseProvided(Option<u64>),
-    }
+fn infra(what: &str, msg: *const std::os::raw::c_char) -> error::Error {
+    let msg = if msg.is_null() { "".into() } else { unsafe { CStr::from_ptr(msg) }.to_string_lossy() };
+    error::Error::IoError(io::Error::new(io::ErrorKind::Other, format!("{}: {}", what, msg)))
 }
 
 /// A decoder bound to one GPU.  Creating it fails when no MI355X / HIP runtime is usable: there is no CPU
@@ -118,11 +61,7 @@ impl Context {
         let mut raw = ptr::null_mut();
         let rc = unsafe { ffi::milzma_create(device, &mut raw) };
         if rc != ffi::MILZMA_OK {
-            let msg = unsafe { CStr::from_ptr(ffi::milzma_last_error(ptr::null())) };
-            return Err(error::Error::IoError(io::Error::new(
-                io::ErrorKind::Other,
-                format!("milzma_create: {}", msg.to_string_lossy()),
-            )));
+            return Err(infra("milzma_create", unsafe { ffi::milzma_last_error(ptr::null()) }));
         }
         Ok(Context { raw })
     }
@@ -134,19 +73,56 @@ impl Drop for Context {
     }
 }
 
-thread_local! {
-    static DEFAULT_CTX: std::cell::RefCell<Option<Context>> = std::cell::RefCell::new(None);
+/// The GPUs of one node behind one handle: one context and one host worker thread per device, a call's files
+/// partitioned by size (`milzma_partition`), each device fed over its own PCIe link, all concurrently.
+pub struct MultiContext {
+    raw: *mut ffi::milzma_multi,
 }
 
+unsafe impl Send for MultiContext {}
+
+impl MultiContext {
+    /// `device_mask`: bit d = HIP ordinal d; 0 = every visible device.
+    pub fn new(device_mask: u64) -> error::Result<MultiContext> {
+        let mut raw = ptr::null_mut();
+        let rc = unsafe { ffi::milzma_multi_create(device_mask, &mut raw) };
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_multi_create", unsafe { ffi::milzma_multi_last_error(ptr::null()) }));
+        }
+        Ok(MultiContext { raw })
+    }
+
+    /// HIP ordinals of the devices behind this handle.
+    pub fn devices(&self) -> Vec<i32> {
+        let n = unsafe { ffi::milzma_multi_devices(self.raw, ptr::null_mut(), 0) };
+        let mut v = vec![0i32; n as usize];
+        unsafe { ffi::milzma_multi_devices(self.raw, v.as_mut_ptr(), n) };
+        v
+    }
+}
+
+impl Drop for MultiContext {
+    fn drop(&mut self) {
+        unsafe { ffi::milzma_multi_destroy(self.raw) }
+    }
+}
+
+thread_local! {
+    static DEFAULT_CTX: std::cell::RefCell<Option<Rc<Context>>> = std::cell::RefCell::new(None);
+}
+
+/// The calling thread's context on device `MILZMA_DEVICE` (default 0).  The `RefCell` is only borrowed to fetch the
+/// handle: `f` -- which runs the caller's `Write` -- may itself decode on this thread.
 fn with_default_ctx<T>(f: impl FnOnce(&Context) -> error::Result<T>) -> error::Result<T> {
-    DEFAULT_CTX.with(|slot| {
+    let ctx = DEFAULT_CTX.with(|slot| -> error::Result<Rc<Context>> {
         let mut slot = slot.borrow_mut();
         if slot.is_none() {
             let device = std::env::var("MILZMA_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-            *slot = Some(Context::new(device)?);
+            *slot = Some(Rc::new(Context::new(device)?));
         }
-        f(slot.as_ref().unwrap())
-    })
+        Ok(slot.as_ref().unwrap().clone())
+    })?;
+    f(&ctx)
 }
 
 fn c_options(o: &decompress::Options) -> ffi::milzma_options {
@@ -166,12 +142,8 @@ fn c_options(o: &decompress::Options) -> ffi::milzma_options {
     }
 }
 
-/// Runs `decode` on what `input` holds and hands the verdict to `output` / `input` the way the reference would.
-///
-/// First on the bytes one `fill_buf` shows, WITHOUT consuming: for a slice or a `Cursor` that is the whole input, and
-/// afterwards exactly `in_consumed` bytes are consumed -- the reference's reader position.  Only if that attempt ends
-/// in an error and the reader turns out to hold more (a `BufReader` over a file larger than its buffer), everything
-/// is read and decoded again; such a reader is then left at its end (see the module note).
+/// Runs `decode` on what `input` holds and hands the verdict to `output` / `input` the way the reference would
+/// (the two cases of the module note).
 fn run<R: io::BufRead, W: io::Write>(
     input: &mut R,
     output: &mut W,
@@ -180,24 +152,28 @@ fn run<R: io::BufRead, W: io::Write>(
     let first = input.fill_buf()?.to_vec();
     let mut out = empty_output();
     decode(&first, &mut out);
-    if out.kind == ffi::MILZMA_OK {
+    if out.in_consumed < first.len() {
+        // decided inside the view: nothing after it can change the verdict
         return deliver(&mut out, input, false, output);
     }
-    // an error: truncation by the reader's buffer, or the stream's own?
+    // the decoder reached the end of the view: the reader's end, or only its buffer's?
     input.consume(first.len());
-    let mut rest = Vec::new();
-    input.read_to_end(&mut rest)?;
-    if rest.is_empty() {
+    if input.fill_buf()?.is_empty() {
         return deliver(&mut out, input, true, output);
     }
-    if !out.data.is_null() {
-        unsafe { ffi::milzma_free(out.data as *mut _) };
-    }
+    release(&mut out);
     let mut all = first;
-    all.extend_from_slice(&rest);
+    input.read_to_end(&mut all)?;
     let mut out = empty_output();
     decode(&all, &mut out);
     deliver(&mut out, input, true, output)
+}
+
+fn release(out: &mut ffi::milzma_output) {
+    if !out.data.is_null() {
+        unsafe { ffi::milzma_free(out.data as *mut _) };
+        out.data = ptr::null_mut();
+    }
 }
 
 /// Hands the library's verdict to the caller's writer / reader the way the reference would have.
@@ -209,10 +185,7 @@ fn deliver<R: io::BufRead, W: io::Write>(
 ) -> error::Result<()> {
     let data = if out.len == 0 { &[][..] } else { unsafe { std::slice::from_raw_parts(out.data, out.len) } };
     let wrote = output.write_all(data).and_then(|_| output.flush());
-    if !out.data.is_null() {
-        unsafe { ffi::milzma_free(out.data as *mut _) };
-        out.data = ptr::null_mut();
-    }
+    release(out);
     if !already_consumed {
         input.consume(out.in_consumed);
     }
@@ -281,41 +254,124 @@ pub struct Decoded {
     pub result: error::Result<()>,
 }
 
-fn collect(outs: Vec<ffi::milzma_output>) -> Vec<Decoded> {
+/// `rc`: the batch call's own return code.  MILZMA_INFRA_ERROR there means the library could not run the batch (no
+/// memory, a HIP failure): no file of it may pass as decoded, whatever its slot happens to hold.
+fn collect(rc: i32, why: impl Fn() -> error::Error, outs: Vec<ffi::milzma_output>) -> Vec<Decoded> {
     outs.into_iter()
         .map(|mut o| {
             let mut data = Vec::new();
             let mut no_reader: &[u8] = &[];
-            let result = deliver(&mut o, &mut no_reader, true, &mut data);
+            let mut result = deliver(&mut o, &mut no_reader, true, &mut data);
+            if rc != ffi::MILZMA_OK && result.is_ok() {
+                data.clear();
+                result = Err(why());
+            }
             Decoded { data, in_consumed: o.in_consumed, result }
         })
         .collect()
 }
 
+fn views(files: &[&[u8]]) -> (Vec<*const u8>, Vec<usize>, Vec<ffi::milzma_output>) {
+    (
+        files.iter().map(|f| f.as_ptr()).collect(),
+        files.iter().map(|f| f.len()).collect(),
+        (0..files.len()).map(|_| empty_output()).collect(),
+    )
+}
+
 /// Many complete `.lzma` files in one launch (every stream is one wavefront): what the GPU is for.
 pub fn lzma_decompress_batch(ctx: &Context, files: &[&[u8]], options: &decompress::Options) -> Vec<Decoded> {
-    let ptrs: Vec<*const u8> = files.iter().map(|f| f.as_ptr()).collect();
-    let lens: Vec<usize> = files.iter().map(|f| f.len()).collect();
-    let mut outs: Vec<ffi::milzma_output> = (0..files.len()).map(|_| empty_output()).collect();
+    let (ptrs, lens, mut outs) = views(files);
     let opt = c_options(options);
-    unsafe { ffi::milzma_lzma_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), &opt, outs.as_mut_ptr()) };
-    collect(outs)
+    let rc = unsafe { ffi::milzma_lzma_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), &opt, outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_lzma_decompress_batch", unsafe { ffi::milzma_last_error(ctx.raw) }), outs)
 }
 
 /// Many complete LZMA2 streams in one launch.
 pub fn lzma2_decompress_batch(ctx: &Context, files: &[&[u8]]) -> Vec<Decoded> {
-    let ptrs: Vec<*const u8> = files.iter().map(|f| f.as_ptr()).collect();
-    let lens: Vec<usize> = files.iter().map(|f| f.len()).collect();
-    let mut outs: Vec<ffi::milzma_output> = (0..files.len()).map(|_| empty_output()).collect();
-    unsafe { ffi::milzma_lzma2_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
-    collect(outs)
+    let (ptrs, lens, mut outs) = views(files);
+    let rc = unsafe { ffi::milzma_lzma2_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_lzma2_decompress_batch", unsafe { ffi::milzma_last_error(ctx.raw) }), outs)
 }
 
 /// Many complete `.xz` files in one launch (every block of every file is one wavefront).
 pub fn xz_decompress_batch(ctx: &Context, files: &[&[u8]]) -> Vec<Decoded> {
-    let ptrs: Vec<*const u8> = files.iter().map(|f| f.as_ptr()).collect();
-    let lens: Vec<usize> = files.iter().map(|f| f.len()).collect();
-    let mut outs: Vec<ffi::milzma_output> = (0..files.len()).map(|_| empty_output()).collect();
-    unsafe { ffi::milzma_xz_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
-    collect(outs)
+    let (ptrs, lens, mut outs) = views(files);
+    let rc = unsafe { ffi::milzma_xz_decompress_batch(ctx.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_xz_decompress_batch", unsafe { ffi::milzma_last_error(ctx.raw) }), outs)
+}
+
+/// The same three over every GPU of a [`MultiContext`]: files partitioned by size, one launch per device, concurrently.
+pub fn lzma_decompress_batch_multi(m: &MultiContext, files: &[&[u8]], options: &decompress::Options) -> Vec<Decoded> {
+    let (ptrs, lens, mut outs) = views(files);
+    let opt = c_options(options);
+    let rc = unsafe { ffi::milzma_multi_lzma_decompress_batch(m.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), &opt, outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_multi_lzma_decompress_batch", unsafe { ffi::milzma_multi_last_error(m.raw) }), outs)
+}
+
+pub fn lzma2_decompress_batch_multi(m: &MultiContext, files: &[&[u8]]) -> Vec<Decoded> {
+    let (ptrs, lens, mut outs) = views(files);
+    let rc = unsafe { ffi::milzma_multi_lzma2_decompress_batch(m.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_multi_lzma2_decompress_batch", unsafe { ffi::milzma_multi_last_error(m.raw) }), outs)
+}
+
+pub fn xz_decompress_batch_multi(m: &MultiContext, files: &[&[u8]]) -> Vec<Decoded> {
+    let (ptrs, lens, mut outs) = views(files);
+    let rc = unsafe { ffi::milzma_multi_xz_decompress_batch(m.raw, files.len() as u32, ptrs.as_ptr(), lens.as_ptr(), outs.as_mut_ptr()) };
+    collect(rc, || infra("milzma_multi_xz_decompress_batch", unsafe { ffi::milzma_multi_last_error(m.raw) }), outs)
+}
+
+#[cfg(test)]
+mod tests {
+    //! Need an MI355X and libmilzma.so (README.md).  The streams are literal-only ones written by the crate's own encoder.
+    use super::*;
+    use std::io::{BufRead, BufReader, Cursor};
+
+    fn known_size_stream(plain: &[u8]) -> Vec<u8> {
+        let mut comp = Vec::new();
+        let opts = lzma_rs::compress::Options { unpacked_size: lzma_rs::compress::UnpackedSize::WriteToHeader(Some(plain.len() as u64)) };
+        lzma_rs::lzma_compress_with_options(&mut &plain[..], &mut comp, &opts).unwrap();
+        comp
+    }
+
+    /// A known-size `.lzma` stream followed by other bytes in a `Cursor`: the reader must stand where the reference
+    /// leaves it (the crate's own decoder is run beside ours for the position), the trailing bytes untouched.
+    #[test]
+    fn cursor_position_after_a_known_size_stream_with_trailing_bytes() {
+        let plain = b"the reader stops where the stream stops".repeat(50);
+        let mut file = known_size_stream(&plain);
+        let stream_len = file.len();
+        file.extend_from_slice(b"TRAILING-BYTES");
+        let (mut ours, mut theirs) = (Cursor::new(&file[..]), Cursor::new(&file[..]));
+        let (mut out_ours, mut out_theirs) = (Vec::new(), Vec::new());
+        lzma_decompress(&mut ours, &mut out_ours).unwrap();
+        lzma_rs::lzma_decompress(&mut theirs, &mut out_theirs).unwrap();
+        assert_eq!(out_ours, plain);
+        assert_eq!(out_ours, out_theirs);
+        assert_eq!(ours.position(), theirs.position());
+        assert!(ours.position() as usize <= stream_len);
+        assert!(ours.fill_buf().unwrap().ends_with(b"TRAILING-BYTES"));
+    }
+
+    /// A `BufReader` whose buffer (64 bytes) is far smaller than the stream, unknown size (marker mode): the first view
+    /// ends mid-stream; the verdict must come from the whole input.
+    #[test]
+    fn bufreader_over_a_file_larger_than_its_buffer() {
+        let plain: Vec<u8> = (0..200_000u32).map(|i| (i * 7 % 251) as u8).collect();
+        let mut comp = Vec::new();
+        lzma_rs::lzma_compress(&mut &plain[..], &mut comp).unwrap();
+        assert!(comp.len() > 4096);
+        let mut rd = BufReader::with_capacity(64, Cursor::new(comp));
+        let mut out = Vec::new();
+        lzma_decompress(&mut rd, &mut out).unwrap();
+        assert_eq!(out, plain);
+        // and an error inside the first view leaves a slice reader exactly where the reference does
+        let mut bad = known_size_stream(b"abcdefgh");
+        bad[0] = 0xFF; // invalid properties byte
+        let (mut ours, mut theirs) = (&bad[..], &bad[..]);
+        let e1 = lzma_decompress(&mut ours, &mut Vec::new()).unwrap_err();
+        let e2 = lzma_rs::lzma_decompress(&mut theirs, &mut Vec::new()).unwrap_err();
+        assert_eq!(e1.to_string(), e2.to_string());
+        assert_eq!(ours.len(), theirs.len());
+    }
 }

@@ -138,6 +138,9 @@ EXPORTS = [
     "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
     "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
     "milzma_lzma_read_header", "milzma_crc32", "milzma_crc64", "milzma_xz_plan",
+    "milzma_multi_create", "milzma_multi_destroy", "milzma_multi_devices", "milzma_multi_last_error",
+    "milzma_multi_last_kernel_ms", "milzma_partition", "milzma_multi_decode_units_host", "milzma_multi_decode_units",
+    "milzma_multi_lzma_decompress_batch", "milzma_multi_lzma2_decompress_batch", "milzma_multi_xz_decompress_batch",
 ]
 
 _lib = None
@@ -189,6 +192,22 @@ def lib():
     L.milzma_lzma_read_header.argtypes = [vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(Unit),
                                           ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
     L.milzma_xz_plan.argtypes = [vp, sz, ctypes.POINTER(Unit), u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.milzma_multi_create.argtypes = [u64, ctypes.POINTER(vp)]
+    L.milzma_multi_destroy.argtypes = [vp]
+    L.milzma_multi_devices.restype = u32
+    L.milzma_multi_devices.argtypes = [vp, ctypes.POINTER(ctypes.c_int), u32]
+    L.milzma_multi_last_error.restype = ctypes.c_char_p
+    L.milzma_multi_last_error.argtypes = [vp]
+    L.milzma_multi_last_kernel_ms.restype = ctypes.c_float
+    L.milzma_multi_last_kernel_ms.argtypes = [vp, u32, ctypes.POINTER(u32)]
+    L.milzma_partition.argtypes = [ctypes.POINTER(u64), ctypes.POINTER(u32), u32, u32, ctypes.POINTER(u32)]
+    L.milzma_multi_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz, ctypes.POINTER(Result)]
+    L.milzma_multi_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, ctypes.POINTER(u32), ctypes.POINTER(vp),
+                                            ctypes.POINTER(vp), ctypes.POINTER(Result)]
+    L.milzma_multi_lzma_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                                     ctypes.POINTER(_COptions), ctypes.POINTER(_COutput)]
+    L.milzma_multi_lzma2_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
+    L.milzma_multi_xz_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
     L.milzma_crc32.restype = u32
     L.milzma_crc32.argtypes = [vp, sz]
     L.milzma_crc64.restype = u64
@@ -363,6 +382,96 @@ class Context:
 
     def xz_batch(self, datas):
         return self._batch(lib().milzma_xz_decompress_batch, datas)
+
+
+def partition(weights, parts, groups=None):
+    """milzma_partition: part index of every item (longest-processing-time-first by weight; items sharing a
+    non-zero group id stay together).  Needs no GPU."""
+    n = len(weights)
+    w = (ctypes.c_uint64 * max(n, 1))(*weights)
+    g = (ctypes.c_uint32 * max(n, 1))(*groups) if groups is not None else None
+    out = (ctypes.c_uint32 * max(n, 1))()
+    if lib().milzma_partition(w, g, n, parts, out) != OK:
+        raise InfraError("milzma_partition: bad arguments")
+    return list(out)[:n]
+
+
+class MultiContext:
+    """milzma_multi: the GPUs of one node behind one handle (one context + one host worker thread per device).
+    device_mask: bit d = HIP ordinal d, 0 = every visible device."""
+
+    def __init__(self, device_mask=0):
+        self._h = ctypes.c_void_p()
+        L = lib()
+        if L.milzma_multi_create(device_mask, ctypes.byref(self._h)) != OK:
+            raise InfraError("milzma_multi_create failed: " + (L.milzma_multi_last_error(None) or b"").decode())
+        n = L.milzma_multi_devices(self._h, None, 0)
+        ords = (ctypes.c_int * n)()
+        L.milzma_multi_devices(self._h, ords, n)
+        self.devices = list(ords)
+
+    def close(self):
+        if self._h:
+            lib().milzma_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return (lib().milzma_multi_last_error(self._h) or b"").decode()
+
+    def kernel_ms(self, k=0xFFFFFFFF):
+        launches = ctypes.c_uint32()
+        return lib().milzma_multi_last_kernel_ms(self._h, k, ctypes.byref(launches)), launches.value
+
+    def decode_units_host(self, units, h_in, out_bytes):
+        n = len(units)
+        results = (Result * n)()
+        pin, nin, keep = _as_buffer(h_in)
+        out = (ctypes.c_char * max(out_bytes, 1))()
+        r = lib().milzma_multi_decode_units_host(self._h, units, n, pin, nin, ctypes.cast(out, ctypes.c_void_p), out_bytes, results)
+        del keep
+        if r != OK:
+            raise InfraError("milzma_multi_decode_units_host: " + self.last_error())
+        return results, bytearray(out)[:out_bytes]
+
+    def decode_units(self, units, device_of, d_ins, d_outs):
+        """units: ctypes array; device_of: device index per unit; d_ins / d_outs: device pointer (int) per device."""
+        n = len(units)
+        results = (Result * n)()
+        dev = (ctypes.c_uint32 * max(n, 1))(*device_of)
+        nd = len(self.devices)
+        pin = (ctypes.c_void_p * nd)(*d_ins)
+        pout = (ctypes.c_void_p * nd)(*d_outs)
+        if lib().milzma_multi_decode_units(self._h, units, n, dev, pin, pout, results) != OK:
+            raise InfraError("milzma_multi_decode_units: " + self.last_error())
+        return results
+
+    def _batch(self, fn, datas, options=None, with_options=False):
+        n = len(datas)
+        bufs = [_as_buffer(d) for d in datas]
+        ptrs = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+        lens = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+        outs = (_COutput * n)()
+        if with_options:
+            o = _c_options(options)
+            fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
+        else:
+            fn(self._h, n, ptrs, lens, outs)
+        return [Decoded(outs[i]) for i in range(n)]
+
+    def lzma_batch(self, datas, options=None):
+        return self._batch(lib().milzma_multi_lzma_decompress_batch, datas, options, True)
+
+    def lzma2_batch(self, datas):
+        return self._batch(lib().milzma_multi_lzma2_decompress_batch, datas)
+
+    def xz_batch(self, datas):
+        return self._batch(lib().milzma_multi_xz_decompress_batch, datas)
 
 
 _default_ctx = None

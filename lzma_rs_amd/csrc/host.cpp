@@ -1773,3 +1773,334 @@ extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results)
     return MILZMA_INFRA_ERROR;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// several GPUs of one node: one context + one host worker per device, work partitioned by
+// compressed bytes (every public entry point of the reference builds a fresh decoder,
+// src/lib.rs:44-105: streams / LZMA2 groups / XZ blocks never exchange anything)
+// ------------------------------------------------------------------------------------------
+
+struct milzma_multi {
+  std::vector<milzma_ctx*> ctx;
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+// Longest-processing-time-first over (grouped) items; see milzma_partition in the header.
+int partition_impl(const uint64_t* weights, const uint32_t* group, uint32_t n, uint32_t parts, uint32_t* part_of) {
+  if (!part_of || parts == 0 || (n && !weights)) return MILZMA_INFRA_ERROR;
+  struct Item {
+    uint64_t w;
+    uint32_t first;  // lowest member index (tie-break and determinism)
+    std::vector<uint32_t> members;
+  };
+  std::vector<Item> items;
+  std::unordered_map<uint32_t, size_t> of_group;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t g = group ? group[i] : 0;
+    if (g) {
+      auto it = of_group.find(g);
+      if (it != of_group.end()) {
+        items[it->second].w += weights[i];
+        items[it->second].members.push_back(i);
+        continue;
+      }
+      of_group[g] = items.size();
+    }
+    items.push_back(Item{weights[i], i, {i}});
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.w != b.w ? a.w > b.w : a.first < b.first; });
+  std::vector<uint64_t> load(parts, 0);
+  for (const Item& it : items) {
+    uint32_t best = 0;
+    for (uint32_t p = 1; p < parts; p++)
+      if (load[p] < load[best]) best = p;
+    load[best] += it.w;
+    for (uint32_t i : it.members) part_of[i] = best;
+  }
+  return MILZMA_OK;
+}
+
+// runs fn(k) for every device index k on its own thread (the calling thread takes the last one)
+template <class F>
+void per_device(size_t nd, F fn) {
+  std::vector<std::thread> th;
+  for (size_t k = 0; k + 1 < nd; k++) th.emplace_back([=] { fn(k); });
+  if (nd) fn(nd - 1);
+  for (auto& t : th) t.join();
+}
+
+int multi_fail(milzma_multi* m, const std::string& why) {
+  if (m) m->err = why;
+  return MILZMA_INFRA_ERROR;
+}
+
+// Whole-file batch over the devices: files partitioned by size, each device runs the single-device entry point on its share.
+template <class Call>
+int multi_file_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, milzma_output* outs, Call call) {
+  if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  if (n == 0) return MILZMA_OK;
+  if (!ins || !in_lens || !outs) return multi_fail(m, "null argument");
+  const uint32_t nd = uint32_t(m->ctx.size());
+  std::vector<uint64_t> w(n);
+  for (uint32_t i = 0; i < n; i++) w[i] = in_lens[i];
+  std::vector<uint32_t> part(n);
+  partition_impl(w.data(), nullptr, n, nd, part.data());
+  std::vector<std::vector<uint32_t>> share(nd);
+  for (uint32_t i = 0; i < n; i++) share[part[i]].push_back(i);
+  std::vector<int> rc(nd, MILZMA_OK);
+  per_device(nd, [&](size_t k) {
+    const std::vector<uint32_t>& idx = share[k];
+    if (idx.empty()) return;
+    std::vector<const uint8_t*> sub_in(idx.size());
+    std::vector<size_t> sub_len(idx.size());
+    std::vector<milzma_output> sub_out(idx.size());
+    for (size_t j = 0; j < idx.size(); j++) {
+      sub_in[j] = ins[idx[j]];
+      sub_len[j] = in_lens[idx[j]];
+    }
+    rc[k] = call(m->ctx[k], uint32_t(idx.size()), sub_in.data(), sub_len.data(), sub_out.data());
+    for (size_t j = 0; j < idx.size(); j++) outs[idx[j]] = sub_out[j];
+  });
+  for (uint32_t k = 0; k < nd; k++)
+    if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
+  return MILZMA_OK;
+}
+
+}  // namespace
+
+extern "C" int milzma_partition(const uint64_t* weights, const uint32_t* group, uint32_t n, uint32_t parts, uint32_t* part_of) {
+  try {
+    return partition_impl(weights, group, n, parts, part_of);
+  } catch (const std::exception&) {
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_multi_create(uint64_t device_mask, milzma_multi** out) {
+  if (!out) return MILZMA_INFRA_ERROR;
+  *out = nullptr;
+  try {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+      (void)hipGetLastError();
+      g_multi_create_error = "no usable HIP device (this library has no CPU decode path)";
+      return MILZMA_INFRA_ERROR;
+    }
+    if (device_mask == 0) device_mask = count >= 64 ? ~uint64_t(0) : ((uint64_t(1) << count) - 1);
+    auto* m = new milzma_multi();
+    for (int d = 0; d < 64; d++) {
+      if (!((device_mask >> d) & 1)) continue;
+      milzma_ctx* c = nullptr;
+      if (d >= count || milzma_create(d, &c) != MILZMA_OK) {
+        g_multi_create_error = "device " + std::to_string(d) + ": " + (d >= count ? std::string("not present") : g_create_error);
+        milzma_multi_destroy(m);
+        return MILZMA_INFRA_ERROR;
+      }
+      m->ctx.push_back(c);
+    }
+    *out = m;
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    g_multi_create_error = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" void milzma_multi_destroy(milzma_multi* m) {
+  if (!m) return;
+  for (milzma_ctx* c : m->ctx) milzma_destroy(c);
+  delete m;
+}
+
+extern "C" uint32_t milzma_multi_devices(const milzma_multi* m, int* ordinals, uint32_t cap) {
+  if (!m) return 0;
+  for (uint32_t k = 0; ordinals && k < cap && k < m->ctx.size(); k++) ordinals[k] = m->ctx[k]->device;
+  return uint32_t(m->ctx.size());
+}
+
+extern "C" const char* milzma_multi_last_error(const milzma_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+extern "C" float milzma_multi_last_kernel_ms(const milzma_multi* m, uint32_t k, uint32_t* launches) {
+  if (launches) *launches = 0;
+  if (!m) return 0.f;
+  if (k != UINT32_MAX) return k < m->ctx.size() ? milzma_last_kernel_ms(m->ctx[k], launches) : 0.f;
+  float best = 0.f;
+  for (milzma_ctx* c : m->ctx) {
+    uint32_t l = 0;
+    const float ms = milzma_last_kernel_ms(c, &l);
+    if (ms >= best) {
+      best = ms;
+      if (launches) *launches = l;
+    }
+  }
+  return best;
+}
+
+extern "C" int milzma_multi_decode_units(milzma_multi* m, const milzma_unit* units, uint32_t n, const uint32_t* device_of,
+                                         const void* const* d_in, void* const* d_out, milzma_result* results) {
+  if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  try {
+    if (n == 0) return MILZMA_OK;
+    if (!units || !device_of || !d_in || !d_out || !results) return multi_fail(m, "null argument");
+    const uint32_t nd = uint32_t(m->ctx.size());
+    std::vector<std::vector<uint32_t>> share(nd);
+    for (uint32_t i = 0; i < n; i++) {
+      if (device_of[i] >= nd) return multi_fail(m, "unit " + std::to_string(i) + ": device index out of range");
+      share[device_of[i]].push_back(i);
+    }
+    std::vector<int> rc(nd, MILZMA_OK);
+    per_device(nd, [&](size_t k) {
+      const std::vector<uint32_t>& idx = share[k];
+      if (idx.empty()) {
+        m->ctx[k]->last_ms = 0.f;
+        m->ctx[k]->last_launches = 0;
+        return;
+      }
+      std::vector<milzma_unit> sub(idx.size());
+      std::vector<milzma_result> res(idx.size());
+      for (size_t j = 0; j < idx.size(); j++) sub[j] = units[idx[j]];
+      rc[k] = milzma_decode_units(m->ctx[k], sub.data(), uint32_t(sub.size()), d_in[k], d_out[k], res.data(), nullptr);
+      if (rc[k] == MILZMA_OK)
+        for (size_t j = 0; j < idx.size(); j++) results[idx[j]] = res[j];
+    });
+    for (uint32_t k = 0; k < nd; k++)
+      if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}
+
+extern "C" int milzma_multi_decode_units_host(milzma_multi* m, const milzma_unit* units, uint32_t n, const void* h_in, size_t in_bytes,
+                                              void* h_out, size_t out_bytes, milzma_result* results) {
+  if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  try {
+    if (n == 0) return MILZMA_OK;
+    if (!units || !results || (in_bytes && !h_in) || (out_bytes && !h_out)) return multi_fail(m, "null argument");
+    // the same descriptor checks as milzma_decode_units_host: nothing leaves the caller's buffers, no two outputs overlap
+    {
+      std::vector<std::pair<uint64_t, uint64_t>> spans;
+      spans.reserve(n);
+      for (uint32_t i = 0; i < n; i++) {
+        const milzma_unit& u = units[i];
+        if (u.in_off > in_bytes || u.in_len > in_bytes - u.in_off || u.out_off > out_bytes || u.out_cap > out_bytes - u.out_off)
+          return multi_fail(m, "unit " + std::to_string(i) + ": input or output slice outside the buffers");
+        if (u.out_cap) spans.emplace_back(u.out_off, u.out_off + u.out_cap);
+      }
+      std::sort(spans.begin(), spans.end());
+      for (size_t k = 1; k < spans.size(); k++)
+        if (spans[k].first < spans[k - 1].second) return multi_fail(m, "overlapping output slices");
+    }
+    const uint32_t nd = uint32_t(m->ctx.size());
+    std::vector<uint64_t> w(n);
+    for (uint32_t i = 0; i < n; i++) w[i] = units[i].in_len + 1;
+    std::vector<uint32_t> part(n);
+    partition_impl(w.data(), nullptr, n, nd, part.data());
+    std::vector<std::vector<uint32_t>> share(nd);
+    for (uint32_t i = 0; i < n; i++) share[part[i]].push_back(i);
+    const uint8_t* hin = static_cast<const uint8_t*>(h_in);
+    uint8_t* hout = static_cast<uint8_t*>(h_out);
+    std::vector<int> rc(nd, MILZMA_OK);
+    per_device(nd, [&](size_t k) {
+      milzma_ctx* ctx = m->ctx[k];
+      const std::vector<uint32_t>& idx = share[k];
+      ctx->last_ms = 0.f;
+      ctx->last_launches = 0;
+      if (idx.empty()) return;
+      // this device's share, packed: inputs and output slices at 256-byte aligned offsets of its own staging buffers
+      std::vector<milzma_unit> sub(idx.size());
+      size_t in_total = 0, out_total = 0;
+      for (size_t j = 0; j < idx.size(); j++) {
+        sub[j] = units[idx[j]];
+        sub[j].in_off = in_total;
+        sub[j].out_off = out_total;
+        in_total += round_up(size_t(sub[j].in_len), 256);
+        out_total += round_up(size_t(sub[j].out_cap), 256);
+      }
+      const auto bad = [&](const char* what) {
+        if (what) ctx->err = what;
+        rc[k] = MILZMA_INFRA_ERROR;
+      };
+      if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !pin_reserve(ctx, ctx->pin_in, in_total) ||
+          !pin_reserve(ctx, ctx->pin_out, out_total) || !dev_reserve(ctx, ctx->in, in_total + 512) ||
+          !dev_reserve(ctx, ctx->out, out_total + 512))
+        return bad(nullptr);
+      uint8_t* pin = static_cast<uint8_t*>(ctx->pin_in.p);
+      {  // gather || H2D in eight groups, as in the whole-file batch path
+        const size_t groups = std::min<size_t>(8, sub.size());
+        std::vector<size_t> first(groups + 1), bounds(groups + 1);
+        for (size_t g = 0; g <= groups; g++) {
+          first[g] = sub.size() * g / groups;
+          bounds[g] = g == groups ? in_total : size_t(sub[first[g]].in_off);
+        }
+        if (!staged_h2d(ctx, ctx->in.p, pin, bounds, [&](size_t g) {
+              parallel_for(first[g + 1] - first[g], [&](size_t j0) {
+                const size_t j = first[g] + j0;
+                memcpy(pin + sub[j].in_off, hin + units[idx[j]].in_off, size_t(sub[j].in_len));
+              });
+            }))
+          return bad(nullptr);
+      }
+      std::vector<milzma_result> res(sub.size());
+      if (milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK)
+        return bad(nullptr);
+      ChunkedCopy d2h;
+      if (!d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_total)) return bad(nullptr);
+      const uint8_t* pout = static_cast<const uint8_t*>(ctx->pin_out.p);
+      std::vector<uint8_t> failed(sub.size(), 0);
+      parallel_for(sub.size(), [&](size_t j) {
+        const size_t got = size_t(std::min<uint64_t>(res[j].out_len, sub[j].out_cap));
+        if (!d2h.wait_until(size_t(sub[j].out_off) + got)) {
+          failed[j] = 1;
+          return;
+        }
+        if (got) memcpy(hout + units[idx[j]].out_off, pout + sub[j].out_off, got);
+        results[idx[j]] = res[j];
+      });
+      for (uint8_t f : failed)
+        if (f) return bad("D2H output failed");
+    });
+    for (uint32_t k = 0; k < nd; k++)
+      if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}
+
+extern "C" int milzma_multi_lzma_decompress_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                  const milzma_options* opt, milzma_output* outs) {
+  try {
+    return multi_file_batch(m, n, ins, in_lens, outs, [opt](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+      return milzma_lzma_decompress_batch(c, k, i, l, opt, o);
+    });
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}
+
+extern "C" int milzma_multi_lzma2_decompress_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                   milzma_output* outs) {
+  try {
+    return multi_file_batch(m, n, ins, in_lens, outs, [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+      return milzma_lzma2_decompress_batch(c, k, i, l, o);
+    });
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}
+
+extern "C" int milzma_multi_xz_decompress_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                milzma_output* outs) {
+  try {
+    return multi_file_batch(m, n, ins, in_lens, outs, [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+      return milzma_xz_decompress_batch(c, k, i, l, o);
+    });
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}

@@ -31,25 +31,15 @@ def init(backend=None):
     return rank, local_rank, world
 
 
-def shard_range(n_units, rank, world):
-    """Contiguous range [lo, hi) of the batch that `rank` decodes; sizes differ by at most one."""
-    base, rem = divmod(n_units, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
-def shard_by_bytes(sizes, world):
-    """Greedy longest-processing-time partition of units by (compressed) size.
+def shard_by_bytes(sizes, world, groups=None):
+    """Partition of units by (compressed) size over `world` ranks: the library's own planner (milzma_partition, the one
+    milzma_multi_* uses in-process: longest-processing-time-first, grouped units stay together).
     Returns a list of index lists, one per rank; every unit appears exactly once."""
-    order = sorted(range(len(sizes)), key=lambda i: -sizes[i])
-    loads = [0] * world
+    import lzma_rs_amd as M
+    part = M.partition(list(sizes), world, groups)
     parts = [[] for _ in range(world)]
-    for i in order:
-        r = min(range(world), key=lambda k: loads[k])
-        parts[r].append(i)
-        loads[r] += sizes[i]
-    for p in parts:
-        p.sort()
+    for i, p in enumerate(part):
+        parts[p].append(i)
     return parts
 
 

@@ -15,25 +15,27 @@ sys.path.insert(0, ROOT)
 from lzma_rs_amd import distributed as D  # noqa: E402
 
 
-def test_shard_range_covers_everything_once():
-    for n in (0, 1, 7, 4096, 4099):
-        for world in (1, 2, 3, 8):
-            seen = []
-            for r in range(world):
-                lo, hi = D.shard_range(n, r, world)
-                assert 0 <= lo <= hi <= n
-                seen.extend(range(lo, hi))
-            assert seen == list(range(n))
-            sizes = [D.shard_range(n, r, world)[1] - D.shard_range(n, r, world)[0] for r in range(world)]
-            assert max(sizes) - min(sizes) <= 1
-
-
-def test_shard_by_bytes_balances():
+def test_partition_planner_through_the_c_symbol():
+    """milzma_partition (the planner behind milzma_multi_* and bench.py --scatter), no GPU needed: every item exactly once,
+    the heaviest part within one item of the lightest, grouped items together, deterministic."""
+    import lzma_rs_amd as M
     sizes = [(i * 7919) % 1000 + 1 for i in range(500)]
-    parts = D.shard_by_bytes(sizes, 4)
-    assert sorted(i for p in parts for i in p) == list(range(500))
-    loads = [sum(sizes[i] for i in p) for p in parts]
-    assert max(loads) - min(loads) <= max(sizes)
+    for world in (1, 2, 3, 4, 8):
+        parts = D.shard_by_bytes(sizes, world)
+        assert sorted(i for p in parts for i in p) == list(range(500))
+        loads = [sum(sizes[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(sizes)
+        assert D.shard_by_bytes(sizes, world) == parts
+    # the blocks of one .xz file / the units of one LZMA2 group are never split
+    groups = [1 + i // 4 if i < 400 else 0 for i in range(500)]
+    part = M.partition(sizes, 8, groups)
+    for g in range(1, 101):
+        assert len({part[i] for i in range(500) if groups[i] == g}) == 1
+    loads = [sum(s for s, p in zip(sizes, part) if p == k) for k in range(8)]
+    assert max(loads) - min(loads) <= 4 * max(sizes)
+    assert M.partition([], 3) == [] and M.partition([7], 1) == [0]
+    with pytest.raises(M.InfraError):
+        M.partition([1, 2], 0)
 
 
 def _free_port():
@@ -89,7 +91,8 @@ def test_two_ranks_gloo():
 
 def test_bench_rank_logic_two_ranks_gloo():
     """bench.py's multi-rank path up to (not including) the first decode, world size 2 over gloo on CPU: generation
-    per rank, process-group rendezvous, input scatter, barrier and the max-over-ranks / sum-over-ranks reductions."""
+    (rank 0's pool in --scatter mode, cut per rank by the library's partition planner), process-group rendezvous, input and
+    descriptor scatter, barrier and the max-over-ranks / sum-over-ranks reductions."""
     import json
     import subprocess
     env = dict(os.environ, MILZMA_DIST_BACKEND="gloo")
@@ -99,6 +102,7 @@ def test_bench_rank_logic_two_ranks_gloo():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["dry_run"] and line["n_gpus"] == 2 and line["units_all_ranks"] == 16 and line["max_time"] == 0.002
+    assert line["distinct_all_ranks"] == 8       # rank 0's pool of 2 x 4 different streams, every one on exactly one rank
 
 
 def test_bench_refuses_more_gpus_than_present():

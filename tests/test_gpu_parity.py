@@ -692,3 +692,83 @@ def test_differential_fuzz_round(ctx):
     for comp, d in zip(cases, ctx.xz_batch(cases)):
         bad += not pf.same("xz", comp, d, orc.xz_decompress(comp))
     assert bad == 0
+
+
+# ---- several GPUs behind one handle (milzma_multi_*): with the devices present (one here) the results must be those of the
+#      single-device entry points, whatever the partition ----------------------------------------------------------------
+def test_multi_device_entry_points_match_single_device(ctx):
+    import ctypes
+    m = M.MultiContext(1)          # mask 1 = device 0
+    try:
+        assert m.devices == [0]
+        rng = random.Random(12)
+        plains = [W.make_plain(rng.choice(["text", "random", "repeat"]), rng.randint(1, 90000), seed=i) for i in range(24)]
+        comps = [W.compress_alone(p, dict_size=1 << 16, known_size=(i % 2 == 0)) for i, p in enumerate(plains)]
+        comps[5] = comps[5][:len(comps[5]) // 2]                     # a truncated one and a damaged one ride along
+        comps[9] = comps[9][:40] + b"\xff" + comps[9][41:]
+        # whole-file batches
+        for a, b in zip(m.lzma_batch(comps), ctx.lzma_batch(comps)):
+            assert (a.kind, a.msg, a.data, a.in_consumed) == (b.kind, b.msg, b.data, b.in_consumed)
+        xzs = [lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64) for p in plains[:8]] + [gold("good-1-lzma2-4.xz")]
+        xzs[3] = xzs[3][:-1] + b"\x00"
+        for a, b in zip(m.xz_batch(xzs), ctx.xz_batch(xzs)):
+            assert (a.kind, a.msg, a.data) == (b.kind, b.msg, b.data)
+        raws = [lzma.compress(p, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}]) for p in plains[:6]]
+        for a, b in zip(m.lzma2_batch(raws), ctx.lzma2_batch(raws)):
+            assert (a.kind, a.msg, a.data, a.in_consumed) == (b.kind, b.msg, b.data, b.in_consumed)
+        # unit level, host-resident: the multi call packs each device's share itself
+        units, blob, out_off = [], bytearray(), 0
+        for comp, p in zip(comps, plains):
+            u, hl = M.lzma_read_header(comp)
+            u.in_off, u.in_len, u.out_off, u.out_cap = len(blob) + 3, len(comp) - hl, out_off, len(p) + 300
+            blob += b"\x00\x00\x00" + comp[hl:]
+            out_off += len(p) + 300 + 17
+            units.append(u)
+        arr = (M.Unit * len(units))(*units)
+        r1, o1 = m.decode_units_host(arr, bytes(blob), out_off)
+        r2, o2 = ctx.decode_units_host(arr, bytes(blob), out_off)
+        for u, a, b in zip(units, r1, r2):
+            assert (a.status, a.out_len, a.out_flushed, a.in_consumed, a.err_a, a.err_b) == (b.status, b.out_len, b.out_flushed, b.in_consumed, b.err_a, b.err_b)
+            n = min(a.out_len, u.out_cap)
+            assert o1[u.out_off:u.out_off + n] == o2[u.out_off:u.out_off + n]
+        # unit level, device-resident
+        import torch
+        d_in = torch.frombuffer(bytearray(blob) + bytearray(512), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(out_off + 512, dtype=torch.uint8, device="cuda")
+        r3 = m.decode_units(arr, [0] * len(units), [d_in.data_ptr()], [d_out.data_ptr()])
+        got = d_out.cpu().numpy().tobytes()
+        for u, a, b in zip(units, r3, r2):
+            assert (a.status, a.out_len, a.in_consumed) == (b.status, b.out_len, b.in_consumed)
+            n = min(a.out_len, u.out_cap)
+            assert got[u.out_off:u.out_off + n] == bytes(o2[u.out_off:u.out_off + n])
+        assert m.kernel_ms()[0] > 0
+        # descriptor checks as in the single-device host call
+        bad = (M.Unit * 1)(units[0])
+        bad[0].in_len = len(blob) + 1
+        with pytest.raises(M.InfraError):
+            m.decode_units_host(bad, bytes(blob), out_off)
+        with pytest.raises(M.InfraError):
+            m.decode_units(arr, [1] * len(units), [d_in.data_ptr()], [d_out.data_ptr()])   # no device index 1 in this handle
+    finally:
+        m.close()
+    with pytest.raises(M.InfraError):
+        M.MultiContext(1 << 40)        # a device that is not there: no partial sets
+
+
+def test_xz_batch_mixes_planned_and_on_demand_blocks_with_a_large_output(ctx):
+    """files whose Index can be planned ahead next to files that must be decoded on demand while the planned output
+    (tens of MiB, several 64 MiB-chunks of D2H) is still coming back: the on-demand decodes reuse the context's output
+    buffer and must not disturb bytes that have not been copied yet (advisor finding, round 2)."""
+    big = [W.make_plain("text", 3 << 20, seed=100 + i) for i in range(24)]
+    files = [W.compress_xz_blocks(p, block_size=1 << 20, dict_size=1 << 16, check="crc64") for p in big]
+    odd_plain = W.make_plain("text", 200000, seed=7)
+    odd = lzma.compress(odd_plain, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32)
+    unplannable = odd[:-2] + b"YY"                       # footer magic broken: no plan, walked (and failed) on demand
+    mixed = [odd] + files[:12] + [unplannable] + files[12:] + [odd]
+    decs = ctx.xz_batch(mixed)
+    want = [odd_plain] + big[:12] + [None] + big[12:] + [odd_plain]
+    for d, w in zip(decs, want):
+        if w is None:
+            same(d, orc.xz_decompress(unplannable))
+        else:
+            assert d.ok and d.data == w

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libmilzma.so does not export " + name
     assert set(M.EXPORTS) == declared
-    assert L.milzma_abi_version() == 1
+    assert L.milzma_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -40,6 +40,8 @@ def test_no_gpu_means_loud_failure_not_fallback():
         pytest.skip("a GPU is present")
     with pytest.raises(M.InfraError):
         M.Context(0)
+    with pytest.raises(M.InfraError):
+        M.MultiContext(0)          # "every visible device" of a node without one
     with pytest.raises(M.InfraError):
         M.lzma_decompress(open(os.path.join(GOLD, "hello.txt.lzma"), "rb").read(), bytearray())
 
