@@ -3,7 +3,9 @@
   xz   (default): configs[4] of BASELINE.json, N .xz files of 4 MiB (text | 200 KB random | text; 1 MiB blocks;
                   CRC64) through milzma_xz_decompress_batch
   lzma:           configs[1] through milzma_lzma_decompress_batch, N .lzma files of 1 MiB
-Usage: python experiments/batch_api_bench.py [files=1024] [distinct=32] [xz|lzma]"""
+After the two single-call runs: `calls` calls of the same batch with TWO in flight (two contexts, milzma_*_batch_async /
+milzma_batch_wait): the copies and the hand-over of one call overlap the decode kernel of the other.
+Usage: python experiments/batch_api_bench.py [files=1024] [distinct=32] [xz|lzma] [calls=2]"""
 import ctypes
 import os
 import sys
@@ -19,6 +21,7 @@ from lzma_rs_amd import workloads as W  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 mode = sys.argv[3] if len(sys.argv) > 3 else "xz"
+calls = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 
 
 def one(i):
@@ -60,3 +63,39 @@ for rep in range(2):
     for i in range(n):
         if outs[i].data:
             lib.milzma_free(ctypes.cast(outs[i].data, ctypes.c_void_p))
+
+
+# ---- `calls` calls, two in flight -------------------------------------------------------------------------------
+ctxs = [ctx, M.Context(0)]
+for ncalls in sorted({2, calls}):
+    slots = [None, None]
+    t0 = time.time()
+    total = ok = 0
+
+    def finish(k):
+        global total, ok
+        rc = lib.milzma_batch_wait(ctxs[k]._h)
+        o = slots[k]
+        assert rc == 0
+        total += sum(o[i].len for i in range(n))
+        ok += sum(1 for i in range(n) if o[i].kind == 0)
+        for i in range(n):
+            if o[i].data:
+                lib.milzma_free(ctypes.cast(o[i].data, ctypes.c_void_p))
+        slots[k] = None
+
+    for c in range(ncalls):
+        k = c % 2
+        if slots[k] is not None:
+            finish(k)
+        slots[k] = (M._COutput * n)()
+        if mode == "lzma":
+            r = lib.milzma_lzma_decompress_batch_async(ctxs[k]._h, n, ptrs, lens, None, slots[k])
+        else:
+            r = lib.milzma_xz_decompress_batch_async(ctxs[k]._h, n, ptrs, lens, slots[k])
+        assert r == 0
+    for k in ((ncalls % 2), 1 - (ncalls % 2)):
+        if slots[k] is not None:
+            finish(k)
+    dt = time.time() - t0
+    print("%d calls x %d files, two in flight: %d ok, %.2f GiB out in %.3f s = %.2f GB/s" % (ncalls, n, ok, total / 2**30, dt, total / dt / 1e9))

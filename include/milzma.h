@@ -204,6 +204,20 @@ int milzma_lzma2_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *co
 int milzma_xz_decompress_batch(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
                                const size_t *in_lens, milzma_output *outs);
 
+/* The batch calls in two halves, so that a caller can keep two of them in flight (two contexts on one device: the
+ * H2D of one call and the D2H + hand-over of the other overlap the decode kernel of whichever holds the GPU; a
+ * 4096-stream kernel fills the chip, so two kernels never overlap).  _async copies the pointer / length arrays and
+ * the options and returns at once; the files' bytes and `outs` must stay valid until milzma_batch_wait(ctx), which
+ * returns what the synchronous call would have returned.  One batch in flight per context. */
+int milzma_lzma_decompress_batch_async(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                                       const size_t *in_lens, const milzma_options *opt,
+                                       milzma_output *outs);
+int milzma_lzma2_decompress_batch_async(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                                        const size_t *in_lens, milzma_output *outs);
+int milzma_xz_decompress_batch_async(milzma_ctx *ctx, uint32_t n, const uint8_t *const *ins,
+                                     const size_t *in_lens, milzma_output *outs);
+int milzma_batch_wait(milzma_ctx *ctx);
+
 /* CRC-32 (ISO-HDLC) and CRC-64/XZ of what each unit decoded, computed on the GPU over the device-resident
  * output of a milzma_decode_units call with the same units / d_out / results: the digest step of
  * validate_block_check (src/decode/xz.rs:292-333) with the polynomials of src/xz/crc.rs:1-4, without a

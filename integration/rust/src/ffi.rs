@@ -191,6 +191,30 @@ extern "C" {
     pub fn milzma_crc32(p: *const u8, n: usize) -> u32;
     pub fn milzma_crc64(p: *const u8, n: usize) -> u64;
 
+    pub fn milzma_lzma_decompress_batch_async(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        opt: *const milzma_options,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_lzma2_decompress_batch_async(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_xz_decompress_batch_async(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        ins: *const *const u8,
+        in_lens: *const usize,
+        outs: *mut milzma_output,
+    ) -> c_int;
+    pub fn milzma_batch_wait(ctx: *mut milzma_ctx) -> c_int;
+
     // ---- several GPUs of one node ------------------------------------------------------------------
     pub fn milzma_multi_create(device_mask: u64, out: *mut *mut milzma_multi) -> c_int;
     pub fn milzma_multi_destroy(m: *mut milzma_multi);

@@ -141,6 +141,8 @@ EXPORTS = [
     "milzma_multi_create", "milzma_multi_destroy", "milzma_multi_devices", "milzma_multi_last_error",
     "milzma_multi_last_kernel_ms", "milzma_partition", "milzma_multi_decode_units_host", "milzma_multi_decode_units",
     "milzma_multi_lzma_decompress_batch", "milzma_multi_lzma2_decompress_batch", "milzma_multi_xz_decompress_batch",
+    "milzma_lzma_decompress_batch_async", "milzma_lzma2_decompress_batch_async", "milzma_xz_decompress_batch_async",
+    "milzma_batch_wait",
 ]
 
 _lib = None
@@ -189,6 +191,10 @@ def lib():
                                                 ctypes.POINTER(_COutput)]
     L.milzma_xz_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
                                              ctypes.POINTER(_COutput)]
+    L.milzma_lzma_decompress_batch_async.argtypes = L.milzma_lzma_decompress_batch.argtypes
+    L.milzma_lzma2_decompress_batch_async.argtypes = L.milzma_lzma2_decompress_batch.argtypes
+    L.milzma_xz_decompress_batch_async.argtypes = L.milzma_xz_decompress_batch.argtypes
+    L.milzma_batch_wait.argtypes = [vp]
     L.milzma_lzma_read_header.argtypes = [vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(Unit),
                                           ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
     L.milzma_xz_plan.argtypes = [vp, sz, ctypes.POINTER(Unit), u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
@@ -382,6 +388,34 @@ class Context:
 
     def xz_batch(self, datas):
         return self._batch(lib().milzma_xz_decompress_batch, datas)
+
+    def batch_async(self, kind, datas, options=None):
+        """milzma_{lzma,lzma2,xz}_decompress_batch_async: returns at once; batch_wait() gives the list of Decoded."""
+        n = len(datas)
+        bufs = [_as_buffer(d) for d in datas]
+        ptrs = (ctypes.c_void_p * n)(*[b[0] for b in bufs])
+        lens = (ctypes.c_size_t * n)(*[b[1] for b in bufs])
+        outs = (_COutput * n)()
+        L = lib()
+        if kind == "lzma":
+            o = _c_options(options)
+            r = L.milzma_lzma_decompress_batch_async(self._h, n, ptrs, lens, ctypes.byref(o), outs)
+        elif kind == "lzma2":
+            r = L.milzma_lzma2_decompress_batch_async(self._h, n, ptrs, lens, outs)
+        else:
+            r = L.milzma_xz_decompress_batch_async(self._h, n, ptrs, lens, outs)
+        if r != OK:
+            raise InfraError("batch_async: " + self.last_error())
+        self._inflight = (bufs, outs, n)
+
+    def batch_wait(self):
+        bufs, outs, n = self._inflight
+        rc = lib().milzma_batch_wait(self._h)
+        self._inflight = None
+        decs = [Decoded(outs[i]) for i in range(n)]
+        if rc != OK:
+            raise InfraError("batch_wait: " + self.last_error())
+        return decs
 
 
 def partition(weights, parts, groups=None):

@@ -62,8 +62,15 @@ struct milzma_ctx {
   std::vector<milzma_unit> pend_units;  // (the caller's array need not outlive the call)
   PinBuf pin_results;
   hipStream_t copy_stream = nullptr;    // chunked staging copies of the whole-file batch entry points
+  hipStream_t work_stream = nullptr;    // decode launches of the whole-file / host-buffer entry points: the context's own
+                                        // stream, so that two contexts with a batch in flight each do not wait for each
+                                        // other's kernels whenever one of them drains "its" stream
   float last_ms = 0.f;
   uint32_t last_launches = 0;
+  // milzma_*_decompress_batch_async: the whole-file batch running on its own host thread until milzma_batch_wait
+  std::thread batch_thread;
+  bool batch_pending = false;
+  int batch_rc = 0;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
   uint32_t lds_pad = 0;  // MILZMA_LDS_PAD: bytes of unused dynamic LDS per block of the fast kernel (occupancy experiments)
@@ -80,6 +87,15 @@ bool hip_ok(milzma_ctx* ctx, hipError_t e, const char* what) {
   else
     g_create_error = buf;
   return false;
+}
+
+// the stream the library's own (host-buffer) entry points launch on; the legacy stream if it cannot be created
+hipStream_t work_stream(milzma_ctx* ctx) {
+  if (!ctx->work_stream && hipStreamCreateWithFlags(&ctx->work_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->work_stream = nullptr;
+  }
+  return ctx->work_stream;
 }
 
 bool dev_reserve(milzma_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -241,6 +257,7 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
 
 extern "C" void milzma_destroy(milzma_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->batch_thread.joinable()) ctx->batch_thread.join();
   (void)hipSetDevice(ctx->device);
   dev_release(ctx->units);
   dev_release(ctx->order);
@@ -255,6 +272,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   pin_release(ctx->pin_small);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
   pin_release(ctx->pin_results);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -509,7 +527,7 @@ static int milzma_decode_units_host_impl(milzma_ctx* ctx, const milzma_unit* uni
   if (!dev_reserve(ctx, ctx->in, in_bytes + 512) || !dev_reserve(ctx, ctx->out, out_bytes + 512)) return MILZMA_INFRA_ERROR;
   if (in_bytes && !hip_ok(ctx, hipMemcpy(ctx->in.p, h_in, in_bytes, hipMemcpyHostToDevice), "H2D input"))
     return MILZMA_INFRA_ERROR;
-  const int r = milzma_decode_units(ctx, units, n, ctx->in.p, ctx->out.p, results, nullptr);
+  const int r = milzma_decode_units(ctx, units, n, ctx->in.p, ctx->out.p, results, work_stream(ctx));
   if (r != MILZMA_OK) return r;
   if (out_bytes && !hip_ok(ctx, hipMemcpy(h_out, ctx->out.p, out_bytes, hipMemcpyDeviceToHost), "D2H output"))
     return MILZMA_INFRA_ERROR;
@@ -857,7 +875,7 @@ bool decode_single(milzma_ctx* ctx, milzma_unit u, const uint8_t* in, size_t in_
         !dev_reserve(ctx, ctx->out, cap + 512))
       return false;
     if (in_len && !hip_ok(ctx, hipMemcpy(ctx->in.p, in, in_len, hipMemcpyHostToDevice), "H2D input")) return false;
-    if (milzma_decode_units(ctx, &u, 1, ctx->in.p, ctx->out.p, &sd->res, nullptr) != MILZMA_OK) return false;
+    if (milzma_decode_units(ctx, &u, 1, ctx->in.p, ctx->out.p, &sd->res, work_stream(ctx)) != MILZMA_OK) return false;
     if (sd->res.status == MILZMA_ST_OUT_FULL && cap < MILZMA_MAX_UNIT_BYTES) {
       cap = cap * 4;
       continue;
@@ -1070,7 +1088,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     std::vector<milzma_result> r(sub.size());
     ChunkedCopy d2h;  // the output comes back in chunks; a stream is handed over as soon as its slice has arrived
     if (!pin_reserve(ctx, ctx->pin_out, out_bytes) || !dev_reserve(ctx, ctx->out, out_bytes + 512) ||
-        milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), nullptr) != MILZMA_OK ||
+        milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), work_stream(ctx)) != MILZMA_OK ||
         !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes)) {
       for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
       finish_alone();
@@ -1585,14 +1603,16 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
             }))
           return false;
       }
-      if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK) return false;
+      hipStream_t ws = work_stream(ctx);
+      if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) return false;
       // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
       return hip_ok(ctx,
                     launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
-                                     static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, nullptr),
+                                     static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, ws),
                     "crc kernel launch") &&
-             hip_ok(ctx, hipMemcpy(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost), "D2H crc parts") &&
-             d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_total);  // in chunks: the walks below start on the first ones
+             hip_ok(ctx, hipMemcpyAsync(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost, ws), "D2H crc parts") &&
+             d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_total) &&  // in chunks: the walks below start on the first ones
+             hip_ok(ctx, hipStreamSynchronize(ws), "hipStreamSynchronize");  // (the CRC parts; the output keeps coming)
     };
     if (ahead()) {
       hout = static_cast<const uint8_t*>(ctx->pin_out.p);
@@ -1720,6 +1740,72 @@ extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uin
     for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
     return MILZMA_INFRA_ERROR;
   }
+}
+
+// ---- the whole-file batch calls in two halves --------------------------------------------------------------------
+namespace {
+
+template <class Call>
+int batch_async(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, milzma_output* outs, Call call) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (ctx->batch_pending) {
+    ctx->err = "a whole-file batch is already in flight on this context: call milzma_batch_wait first";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (n && (!ins || !in_lens || !outs)) {
+    ctx->err = "null argument";
+    return MILZMA_INFRA_ERROR;
+  }
+  try {
+    std::vector<const uint8_t*> p(ins, ins + n);
+    std::vector<size_t> l(in_lens, in_lens + n);
+    ctx->batch_rc = MILZMA_OK;
+    ctx->batch_thread = std::thread([ctx, n, outs, call, p = std::move(p), l = std::move(l)]() {
+      ctx->batch_rc = call(ctx, n, p.data(), l.data(), outs);
+    });
+    ctx->batch_pending = true;
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+}  // namespace
+
+extern "C" int milzma_lzma_decompress_batch_async(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                  const milzma_options* opt, milzma_output* outs) {
+  milzma_options o;
+  milzma_default_options(&o);
+  if (opt) o = *opt;
+  return batch_async(ctx, n, ins, in_lens, outs, [o](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* out) {
+    return milzma_lzma_decompress_batch(c, k, i, l, &o, out);
+  });
+}
+
+extern "C" int milzma_lzma2_decompress_batch_async(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                   milzma_output* outs) {
+  return batch_async(ctx, n, ins, in_lens, outs, [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* out) {
+    return milzma_lzma2_decompress_batch(c, k, i, l, out);
+  });
+}
+
+extern "C" int milzma_xz_decompress_batch_async(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
+                                                milzma_output* outs) {
+  return batch_async(ctx, n, ins, in_lens, outs, [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* out) {
+    return milzma_xz_decompress_batch(c, k, i, l, out);
+  });
+}
+
+extern "C" int milzma_batch_wait(milzma_ctx* ctx) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (!ctx->batch_pending) {
+    ctx->err = "no whole-file batch in flight on this context";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (ctx->batch_thread.joinable()) ctx->batch_thread.join();
+  ctx->batch_pending = false;
+  return ctx->batch_rc;
 }
 
 // Index of a well-formed .xz file -> one LZMA2 unit per block (offsets relative to the file's first byte, out_off / out_cap
@@ -2046,7 +2132,7 @@ extern "C" int milzma_multi_decode_units_host(milzma_multi* m, const milzma_unit
           return bad(nullptr);
       }
       std::vector<milzma_result> res(sub.size());
-      if (milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, res.data(), nullptr) != MILZMA_OK)
+      if (milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, res.data(), work_stream(ctx)) != MILZMA_OK)
         return bad(nullptr);
       ChunkedCopy d2h;
       if (!d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_total)) return bad(nullptr);

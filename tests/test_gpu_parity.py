@@ -772,3 +772,24 @@ def test_xz_batch_mixes_planned_and_on_demand_blocks_with_a_large_output(ctx):
             same(d, orc.xz_decompress(unplannable))
         else:
             assert d.ok and d.data == w
+
+
+def test_whole_file_batches_async_two_in_flight(ctx):
+    """milzma_*_decompress_batch_async / milzma_batch_wait: two contexts, two calls in flight, the results of the synchronous calls"""
+    other = M.Context(0)
+    try:
+        plains = [W.make_plain("text", 30000 + 977 * i, seed=50 + i) for i in range(40)]
+        a = [W.compress_alone(p, dict_size=1 << 16, known_size=True) for p in plains[:20]]
+        b = [lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32) for p in plains[20:]]
+        a[3] = a[3][:100]
+        ctx.batch_async("lzma", a)
+        other.batch_async("xz", b)
+        with pytest.raises(M.InfraError):
+            ctx.batch_async("lzma", a)                 # one batch in flight per context
+        ra, rb = ctx.batch_wait(), other.batch_wait()
+        for x, y in zip(ra, ctx.lzma_batch(a)):
+            assert (x.kind, x.msg, x.data, x.in_consumed) == (y.kind, y.msg, y.data, y.in_consumed)
+        for x, p in zip(rb, plains[20:]):
+            assert x.ok and x.data == p
+    finally:
+        other.close()
