@@ -379,8 +379,9 @@ struct GenericDecoder {
   }
 };
 
-// lit_cap_lclp: largest lc+lp whose literal table fits this launch's LDS (LIT_IN_LDS), else unused.
-// lit_scratch : HBM, (0x300 << 12) u16 per block, used when !LIT_IN_LDS.
+// lit_cap_lclp: largest lc+lp whose literal table fits this launch's LDS (LIT_IN_LDS); for the HBM-spill class the
+//               largest lc+lp among the launch's units: it sizes a block's slice of the scratch slab.
+// lit_scratch : HBM, (0x300 << lit_cap_lclp) u16 per block, used when !LIT_IN_LDS.
 template <bool LIT_IN_LDS>
 __global__ __launch_bounds__(64) void decode_generic_kernel(const milzma_unit* __restrict__ units,
                                                             const uint32_t* __restrict__ order, uint32_t n_units,
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const milzma_unit* _
 
   GenericDecoder<LIT_IN_LDS> d;
   d.model = lds;
-  d.lit = LIT_IN_LDS ? lds + M_SMALL_END : lit_scratch + size_t(blockIdx.x) * (0x300u << 12);
+  d.lit = LIT_IN_LDS ? lds + M_SMALL_END : lit_scratch + size_t(blockIdx.x) * (size_t(0x300u) << lit_cap_lclp);
   d.out = out_base + u.out_off;
   d.status = MILZMA_ST_OK;
   d.err_a = d.err_b = 0;

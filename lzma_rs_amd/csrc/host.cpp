@@ -300,7 +300,10 @@ extern "C" void milzma_default_options(milzma_options* opt) {
 
 namespace {
 
-constexpr uint32_t kSpillBatch = 32;  // blocks per launch of the HBM-spill class (6 MiB scratch each)
+// HBM scratch the spill class (lc + lp > 4) may hold for its literal tables: the slab is sized by the launch's largest
+// lc + lp (1.5 KiB << lclp per block: 384 KiB at lc 8, 6 MiB at lc + lp = 12), and a launch takes as many units as fit
+// (round 2 launched 32 at a time with 6 MiB each whatever their properties: 0.06 GB/s on 4096 streams).
+constexpr size_t kSpillSlabBytes = size_t(24) << 30;
 
 LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   // LZMA2 units start in the cheapest class; NEED_GENERIC / NEED_LCLP promote them when a chunk
@@ -322,8 +325,16 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   auto* d_order = static_cast<const uint32_t*>(ctx->order.p) + order_base;
   auto* d_results = static_cast<milzma_result*>(ctx->results.p);
   const uint32_t n = uint32_t(order.size());
-  const uint32_t step = cls == kLitSpill ? kSpillBatch : n;
-  if (cls == kLitSpill && !dev_reserve(ctx, ctx->scratch, kSpillBytesPerBlock * std::min(n, kSpillBatch))) return false;
+  uint32_t step = n, spill_lclp = 0;
+  if (cls == kLitSpill) {
+    for (uint32_t i : order) spill_lclp = std::max<uint32_t>(spill_lclp, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
+    spill_lclp = std::min<uint32_t>(spill_lclp, 12);
+    size_t free_b = 0, total_b = 0;
+    size_t budget = kSpillSlabBytes;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max(free_b / 2 + ctx->scratch.cap, spill_bytes_per_block(spill_lclp)));
+    step = uint32_t(std::max<size_t>(1, std::min<size_t>(n, budget / spill_bytes_per_block(spill_lclp))));
+    if (!dev_reserve(ctx, ctx->scratch, spill_bytes_per_block(spill_lclp) * step)) return false;
+  }
   for (uint32_t i = 0; i < n; i += step) {
     const uint32_t m = std::min(step, n - i);
     while (ctx->ev_pool.size() < size_t(ctx->ev_used) * 2 + 2) {
@@ -337,7 +348,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
                               ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                             static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
                               : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
-                                                        static_cast<uint16_t*>(ctx->scratch.p), stream);
+                                                        static_cast<uint16_t*>(ctx->scratch.p), spill_lclp, stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
     if (!hip_ok(ctx, hipEventRecord(e1, stream), "hipEventRecord")) return false;
     ctx->ev_used++;  // (timed in collect_kernel_ms once the stream has drained: nothing here waits for the GPU)

@@ -10,20 +10,21 @@ namespace milzma {
 // Launch classes: which kernel, and for the generic one how much of the model lives in LDS.
 enum LitClass : int {
   kFast = 0,      // decode_fast_asm_kernel<8>: lc+lp <= 3 (any pb), model in VGPR lanes, 8 KiB LDS, 16 waves per CU
-  kFastLc4 = 1,   // decode_fast_asm_kernel<16>: lc+lp <= 4 (any pb), 32 literal-table VGPRs, 16 KiB LDS, 9 waves per CU
+  kFastLc4 = 1,   // decode_fast_asm_kernel<16>: lc+lp <= 4 (any pb), 32 literal-table + 16 matched-row VGPRs, 12 KiB LDS, 12 waves per CU
   kLitLds3 = 2,   // generic kernel, literal table for lc+lp <= 3 in LDS (15 984 B per wave: 10 waves per CU)
   kLitLds4 = 3,   // generic kernel, lc+lp <= 4 in LDS (28 272 B per wave: 5 waves per CU)
-  kLitSpill = 4,  // generic kernel, literal table in HBM scratch (lc+lp up to 12), small tables in LDS
+  kLitSpill = 4,  // generic kernel, literal table in an HBM scratch slab sized by the launch's largest lc+lp (up to 12), small tables in LDS
   kNumLitClasses = 5
 };
 
-// bytes of HBM scratch one block of the spill class needs
-constexpr size_t kSpillBytesPerBlock = size_t(0x300u << 12) * sizeof(uint16_t);
+// bytes of HBM scratch one block of the spill class needs when the largest lc + lp of its launch is `lclp` (<= 12)
+constexpr size_t spill_bytes_per_block(uint32_t lclp) { return (size_t(0x300u) << lclp) * sizeof(uint16_t); }
 
 // `order[0..n)` lists the unit indices this launch decodes (one 64-thread block each).
+// spill_lclp: kLitSpill only -- the largest lc + lp among the launch's units (block b's table is at d_scratch + b * (0x300 << spill_lclp)).
 hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
                           const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, uint16_t* d_scratch,
-                          hipStream_t stream);
+                          uint32_t spill_lclp, hipStream_t stream);
 
 // The lane-resident-model kernel (symbol loop in gfx950 asm): lc + lp <= 3 at 16 waves per CU, or (lc4) lc + lp <= 4 at 9.
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,

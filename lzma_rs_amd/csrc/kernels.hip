@@ -9,7 +9,7 @@ namespace milzma {
 
 hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n,
                           const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results, uint16_t* d_scratch,
-                          hipStream_t stream) {
+                          uint32_t spill_lclp, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const dim3 grid(n), block(kWave);
   switch (cls) {
@@ -28,7 +28,7 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
     default: {
       const size_t lds = M_SMALL_END * sizeof(uint16_t);
       hipLaunchKernelGGL(decode_generic_kernel<false>, grid, block, lds, stream, d_units, d_order, n, d_in, d_out,
-                         d_results, 0u, d_scratch);
+                         d_results, spill_lclp, d_scratch);
       break;
     }
   }

@@ -102,3 +102,21 @@ def test_marker_before_a_declared_size(loops):
         lc, lp, pb, ds, us = _hdr(lie)
         r = loops[True].decode_raw(lie[13:], lc, lp, pb, ds, us, out_cap=8192)
         assert r["status"] == "SIZE_MISMATCH" and r["len"] == 5000 and r["in_consumed"] + 13 == ref.in_consumed
+
+
+@pytest.mark.parametrize("lc,lp,pb", [(4, 0, 2), (0, 4, 0), (2, 2, 4)])
+def test_emulated_lc4_rows_in_vgprs(loops, lc, lp, pb):
+    """lc + lp = 4: the matched-literal sub-tables of literal rows 12..15 live in VGPRs (rows 0..11 in LDS).  Bytes >= 0xC0 before
+    a literal that follows a match select those rows: binary data with many short matches goes through both homes."""
+    rnd = random.Random(lc * 10 + lp)
+    blk = rnd.randbytes(4000)
+    plain = b"".join(blk[i:i + rnd.randint(3, 40)] + rnd.randbytes(rnd.randint(1, 6)) for i in range(0, 3900, 17)) + \
+        W.make_plain("text", 20000, seed=1)
+    filt = [{"id": lzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 16}]
+    comp = lzma.compress(plain, format=lzma.FORMAT_ALONE, filters=filt)
+    _check(loops, comp, plain)
+    emu = loops["lc4"]
+    emu.reset_counts()
+    emu.decode_raw(comp[13:], lc, lp, pb, 1 << 16, None, out_cap=len(plain) + 8)
+    c, _ = emu.counts()
+    assert sum(int(c[i]) for i in range(len(c)) if emu.prog.region[i].startswith("LOvrow_load")) > 100

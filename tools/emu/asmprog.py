@@ -190,6 +190,7 @@ class AsmLoop:
         G = self.G
         g = G.Gen(lp0, pb4, lc4)
         self.lit_regs, self.ps0 = G.LIT_REGS, int(G.PS0[1:])  # (this variant's fixed register numbering)
+        self.mvbase = G.MVBASE
         g.build()
         lines = g.main + g.cold + getattr(g, "cold2", []) + g.stubs
         g.cur = lines
@@ -299,6 +300,9 @@ class AsmLoop:
             self.vset(64 + i, 0x04000400)
         for i in range(4):
             self.vset(self.ps0 + i, 0x400)
+        if getattr(G, "MVBASE", None) and self.lit_regs == 32:      # LC4: matched rows 12..15 in VGPRs
+            for i in range(16):
+                self.vset(self.mvbase + i, 0x04000400)
         lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
         self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
         self.vset(self._vidx("v_lane"), lane)

@@ -118,14 +118,15 @@ _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt
            DVT=114, DVA=115, DVX=116, c2017=117, c2048=118)  # temporaries of deferred updates; the constants 2017 and 2048
 if PAD_V:
     _V0["vpad"] = 111
-V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
+V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE = {}, "", "", "", [], 16, None
+VROW0 = 12   # LC4: first matched row that lives in VGPRs
 LIT0, LIT1 = "v64", "v65"   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
 
 
 def set_layout(lc4):
     """Fixed VGPR numbering of a variant: the plain literal table at v64.. (16 dwords for lc + lp <= 3, 32 for lc + lp = 4),
     then the four pos_slot trees (PS0..), then the temporaries and per-lane constants."""
-    global V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS
+    global V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE
     off = 16 if lc4 else 0
     LIT_REGS = 32 if lc4 else 16
     V.clear()
@@ -134,6 +135,9 @@ def set_layout(lc4):
     PS0 = "v%d" % (80 + off)        # pos_slot trees for len_state 0..3
     PS0M2 = "v%d" % (78 + off)      # PS0 - 2: indexed with len_state + 2
     CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
+    # LC4: the matched-literal sub-tables of rows 12..15 live in 16 VGPRs (fixed operands, s_set_gpr_idx indexed), rows 0..11 in
+    # LDS: 12 KiB per wave instead of 16 -> 13 blocks per CU fit, and the 151 VGPRs allow 12 (3 per SIMD); with 16 KiB it was 9
+    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if lc4 else None
 
 
 set_layout(False)
@@ -856,6 +860,48 @@ class Gen:
             self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"], defer=False)
             self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
 
+    def mrow_load(self):
+        """MROW = the matched sub-tables of literal row `row` (4 dwords per lane)"""
+        e, L = self.e, self.L
+        if self.lc4:
+            e("s_cmpk_ge_u32 {row}, %d" % VROW0)
+            e("s_cbranch_scc1 " + L("Ovrow_load"))
+        e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
+        e("ds_read_b128 " + MROW + ", {VA}")
+        e("s_waitcnt lgkmcnt(0)")
+        if self.lc4:
+            self.lab("lm_b")
+            with self.in_cold():
+                self.lab("Ovrow_load")
+                e("s_sub_u32 {t0}, {row}, %d" % VROW0)
+                e("s_lshl_b32 {t0}, {t0}, 2")
+                e("s_set_gpr_idx_on {t0}, gpr_idx(SRC0)")
+                for k in range(4):
+                    e("v_mov_b32 v%d, v%d" % (int(MROW[2:MROW.index(":")]) + k, MVBASE + k))
+                e("s_set_gpr_idx_off")
+                e("s_branch " + L("lm_b"))
+
+    def mrow_store(self):
+        """the row back where it lives (clobbers SCC and t0 in the LC4 variant)"""
+        e, L = self.e, self.L
+        if not self.lc4:
+            e("ds_write_b128 {VA}, " + MROW)
+            return
+        k = self.new("VS")
+        e("s_cmpk_ge_u32 {row}, %d" % VROW0)
+        e("s_cbranch_scc1 " + L(k))
+        e("ds_write_b128 {VA}, " + MROW)
+        self.lab(k + "r")
+        with Gen._Into(self, self.cold2):
+            self.lab(k)
+            e("s_sub_u32 {t0}, {row}, %d" % VROW0)
+            e("s_lshl_b32 {t0}, {t0}, 2")
+            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
+            for j in range(4):
+                e("v_mov_b32 v%d, v%d" % (MVBASE + j, int(MROW[2:MROW.index(":")]) + j))
+            e("s_set_gpr_idx_off")
+            e("s_branch " + L(k + "r"))
+
     def literal_row(self, tag):
         e, L = self.e, self.L
         if self.lp0:
@@ -1071,9 +1117,7 @@ class Gen:
         e("s_cmp_eq_u32 {mb}, -1")
         e("s_cbranch_scc1 " + L("Omb_fetch"))
         lab("lm_a")
-        e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
-        e("ds_read_b128 " + MROW + ", {VA}")
-        e("s_waitcnt lgkmcnt(0)")
+        self.mrow_load()
         # levels 0..6 (a mismatch continues in the plain chain): one code chain per value of the match
         # bit, so that a branch is only taken when the match bit differs from the previous level's
         e("s_bitcmp1_b32 {mb}, 7")
@@ -1100,7 +1144,7 @@ class Gen:
                     lab(mis)
                     e(acc)
                     self.post_known(T, m != 0, half=m)
-                    e("ds_write_b128 {VA}, " + MROW)
+                    self.mrow_store()
                     if i + 1 < 6:
                         e("s_mov_b32 {pl0}, %d" % (i + 1))
                     self.norm(to="plain%d" % (i + 1), kind="lit")
@@ -1121,7 +1165,7 @@ class Gen:
         e("s_addc_u32 {sym}, {sym}, {sym}")
         self.post_sym(V["M2"], half=0)
         lab("lm_full")
-        e("ds_write_b128 {VA}, " + MROW)
+        self.mrow_store()
         self.norm(to="lit_done", kind="lit")
         with self.in_cold():
             for name, T, half, pre, cl in [("lm7_lo_m1", "M2", 1, None, "VLANE128"), ("lm7_hi", "M3", 0, "lm7_hi_m1", "VLANE192"),
@@ -1320,7 +1364,8 @@ def main():
         texts[name] = lines
         clobbers[name] = list(CLOBBER_V)
         fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(LIT_REGS)] +
-                        ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)])
+                        ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)] +
+                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16)] if lc4 else []))
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
