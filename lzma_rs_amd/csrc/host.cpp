@@ -288,7 +288,87 @@ extern "C" float milzma_last_kernel_ms(const milzma_ctx* ctx, uint32_t* launches
   return ctx ? ctx->last_ms : 0.f;
 }
 
-extern "C" void milzma_free(void* p) { free(p); }
+// ---- output buffers: a pool behind out_set_data / milzma_free --------------------------------------------------------
+// A batch call hands back thousands of MiB-sized buffers.  Fresh from malloc each is its own mmap: a million page faults per
+// 4 GiB call (and as many munmaps when the caller frees them), all serialised on the process's mmap lock -- a third of
+// the call's host time.  Buffers freed with milzma_free are kept (by size class, up to MILZMA_POOL_BYTES, default 8 GiB) and
+// handed out again with their pages already mapped.
+namespace {
+
+struct OutHdr {
+  uint64_t magic;
+  uint64_t cap;
+};
+constexpr uint64_t kOutMagic = 0x6D696C7A6D61504Full;  // "milzmaPO"
+
+struct OutPool {
+  std::mutex mu;
+  std::unordered_map<size_t, std::vector<OutHdr*>> free_by_cap;
+  size_t held = 0, limit = size_t(8) << 30;
+  OutPool() {
+    if (const char* e = getenv("MILZMA_POOL_BYTES")) limit = size_t(strtoull(e, nullptr, 0));
+  }
+  ~OutPool() {
+    for (auto& kv : free_by_cap)
+      for (OutHdr* h : kv.second) free(h);
+  }
+};
+OutPool& out_pool() {
+  static OutPool p;
+  return p;
+}
+
+size_t out_class(size_t n) {  // capacity class: powers of two up to 64 KiB, multiples of 64 KiB above
+  if (n <= 4096) return 4096;
+  if (n <= (size_t(1) << 16)) {
+    size_t c = 4096;
+    while (c < n) c <<= 1;
+    return c;
+  }
+  return (n + 0xFFFF) & ~size_t(0xFFFF);
+}
+
+uint8_t* out_alloc(size_t n) {
+  const size_t cap = out_class(n);
+  OutPool& p = out_pool();
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    auto it = p.free_by_cap.find(cap);
+    if (it != p.free_by_cap.end() && !it->second.empty()) {
+      OutHdr* h = it->second.back();
+      it->second.pop_back();
+      p.held -= cap;
+      return reinterpret_cast<uint8_t*>(h + 1);
+    }
+  }
+  auto* h = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
+  if (!h) return nullptr;
+  h->magic = kOutMagic;
+  h->cap = cap;
+  return reinterpret_cast<uint8_t*>(h + 1);
+}
+
+}  // namespace
+
+extern "C" void milzma_free(void* ptr) {
+  if (!ptr) return;
+  OutHdr* h = static_cast<OutHdr*>(ptr) - 1;
+  if (h->magic != kOutMagic) return;  // not one of ours (or freed twice): leave it alone rather than corrupt the heap
+  OutPool& p = out_pool();
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (p.held + h->cap <= p.limit) {
+      try {
+        p.free_by_cap[size_t(h->cap)].push_back(h);
+        p.held += size_t(h->cap);
+        return;
+      } catch (const std::bad_alloc&) {
+      }
+    }
+  }
+  h->magic = 0;
+  free(h);
+}
 
 extern "C" void milzma_default_options(milzma_options* opt) {
   if (opt) memset(opt, 0, sizeof *opt);
@@ -852,7 +932,7 @@ int out_fail(milzma_output* o, int kind, const char* fmt, ...) {
 int out_io_eof(milzma_output* o) { return out_fail(o, MILZMA_IO_ERROR, "%s", kEofMsg); }
 
 bool out_set_data(milzma_output* o, const uint8_t* p, size_t n) {
-  o->data = static_cast<uint8_t*>(malloc(n ? n : 1));
+  o->data = out_alloc(n);
   if (!o->data) return false;
   if (n) memcpy(o->data, p, n);
   o->len = n;
@@ -1245,18 +1325,20 @@ struct Record {
 };
 
 // read_block (src/decode/xz.rs:196-290); block_start = position of the header-size byte
-// The file's output: grows by realloc and is handed to milzma_output as is (milzma_free = free).
+// The file's output: a pooled buffer (out_alloc) that grows by moving and is handed to milzma_output as is.
 struct OutBuf {
   uint8_t* p = nullptr;
   size_t n = 0, cap = 0;
-  ~OutBuf() { free(p); }
+  ~OutBuf() { milzma_free(p); }
   bool reserve(size_t want) {
     if (want <= cap) return true;
     size_t c = std::max(want, cap + cap / 2);
-    c = std::max<size_t>(c, 4096);
-    void* q = realloc(p, c);
+    c = out_class(std::max<size_t>(c, 4096));
+    uint8_t* q = out_alloc(c);
     if (!q) return false;
-    p = static_cast<uint8_t*>(q);
+    if (n) memcpy(q, p, n);
+    milzma_free(p);
+    p = q;
     cap = c;
     return true;
   }
