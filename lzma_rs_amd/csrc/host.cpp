@@ -73,6 +73,7 @@ struct milzma_ctx {
   int batch_rc = 0;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
+  int order_mode = 0;    // MILZMA_ORDER: 0 sorted by input length (default), 1 stride, 2 shuffle (tuning)
   uint32_t lds_pad = 0;  // MILZMA_LDS_PAD: bytes of unused dynamic LDS per block of the fast kernel (occupancy experiments)
 };
 
@@ -243,6 +244,7 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   if (const char* k = getenv("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
   }
+  if (const char* k = getenv("MILZMA_ORDER")) ctx->order_mode = !strcmp(k, "stride") ? 1 : !strcmp(k, "shuffle") ? 2 : 0;
   if (const char* k = getenv("MILZMA_LDS_PAD")) {
     ctx->lds_pad = uint32_t(strtoul(k, nullptr, 0));
   }
@@ -505,6 +507,30 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   for (int c = 0; c < kNumLitClasses; c++) {
     std::stable_sort(order[c].begin(), order[c].end(),
                      [&](uint32_t a, uint32_t b) { return units[a].in_len > units[b].in_len; });
+    // MILZMA_ORDER (tuning): "stride" deals the sorted units out so that any 16 consecutive blocks (about a CU's worth)
+    // hold the whole range of sizes instead of 16 neighbours of the sorted list; "shuffle": a fixed pseudo-random order
+    if (ctx->order_mode && order[c].size() > 32) {
+      std::vector<uint32_t>& o = order[c];
+      const size_t m = o.size();
+      std::vector<uint32_t> p(m);
+      if (ctx->order_mode == 1) {
+        const size_t g = (m + 15) / 16;
+        size_t k = 0;
+        for (size_t r = 0; r < g; r++)
+          for (size_t j = r; j < m; j += g) p[k++] = o[j];
+        // (p lists, for every residue r, the units r, r + g, r + 2g ...: 16 units spread over the whole sorted list)
+      } else {
+        p = o;
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (size_t i = m - 1; i > 0; i--) {
+          x ^= x << 13;
+          x ^= x >> 7;
+          x ^= x << 17;
+          std::swap(p[i], p[size_t(x % (i + 1))]);
+        }
+      }
+      o.swap(p);
+    }
     base[c] = uint32_t(flat.size());
     flat.insert(flat.end(), order[c].begin(), order[c].end());
   }

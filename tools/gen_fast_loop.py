@@ -96,6 +96,11 @@ NORM64 = os.environ.get("MILZMA_GEN_NORM64", "1") == "1"
 # probability updates are queued and emitted into the NEXT decisions' shadows instead of after their own decision:
 #   single = the update of is_match / is_rep / choice ... decisions and of immediate-update tree levels (3 instructions),
 #   tree   = the once-per-walk update of the literal / pos_slot trees (7 instructions).  SHADOW: instructions per shadow.
+# Direct bits without normalisation tests: where the normalisations of a run of n direct bits fall follows from the leading zeros
+# of `range` at its start (the first after 8 - clz halvings, then every 8), so eight pre-laid chains (one per (n + clz) mod 8) carry
+# unconditional inline normalisations at fixed places and 4-instruction bit blocks; the entry address is computed per lane on the
+# vector ALU from tbl_b and clz and fetched with the one v_readlane that fetched the table entry before.
+DIRECT8 = os.environ.get("MILZMA_GEN_DIRECT8", "1") == "1"
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
 if "1" in NORM_S:
@@ -549,13 +554,37 @@ class Gen:
         self.post_known(T, False, defer=defer)
         self.norm(to)
 
-    def direct_bit(self, acc):
-        """RangeDecoder::get_bit (rangecoder.rs:71-82): acc = 2 * acc + (bit == 0)"""
+    def direct_bit(self, acc, test=True):
+        """RangeDecoder::get_bit (rangecoder.rs:71-82): acc = 2 * acc + (bit == 0).  test=False: the caller knows where the
+        normalisations fall (DIRECT8)."""
         self.e("s_lshr_b32 {range}, {range}, 1")
         self.e("s_sub_u32 {sc1}, {code}, {range}")
         self.e("s_cselect_b32 {code}, {code}, {sc1}")
         self.e("s_addc_u32 {a}, {a}, {a}", a=acc)
-        self.norm(kind="direct")
+        if test:
+            self.norm(kind="direct")
+
+    def direct_norm(self, mark=None):
+        """RangeDecoder::normalize (rangecoder.rs:59-69), unconditional and inline: range < 2^24 is known here"""
+        e, L = self.e, self.L
+        k = self.new("DN")
+        if mark:
+            self.lab(mark + "_s")
+        e("s_cmp_eq_u32 {off}, {lim}")
+        e("s_cbranch_scc1 " + L("Xeof"))
+        e("v_readlane_b32 {n1}, {winb}, {off}")
+        e("s_lshl_b64 " + RC + ", " + RC + ", 8")
+        e("s_or_b32 {code}, {code}, {n1}")
+        e("s_add_u32 {off}, {off}, 1")
+        e("s_bitcmp1_b32 {off}, 6")
+        e("s_cbranch_scc1 " + L(k))
+        if mark:
+            self.lab(mark + "_e")
+        self.lab(k + "r")
+        with Gen._Into(self, self.stubs):
+            self.lab(k)
+            e("s_call_b64 " + RET + ", " + L("refill"))
+            e("s_branch " + L(k + "r"))
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False, prof=None, extract=True):
@@ -615,15 +644,25 @@ class Gen:
         e("v_xor_b32 {VT0}, 63, {v_lane}")                 # slot
         e("v_lshrrev_b32 {VT1}, 1, {VT0}")
         e("v_and_b32 {VT2}, 1, {VT0}")
-        e("v_sub_u32 {vt}, 31, {VT1}")                     # 26 - count
-        e("v_mul_u32_u24 {vt}, " + bs + ", {vt}")
-        e("v_add_u32 {tbl_b}, " + L("direct_chain") + "-" + L("base") + ", {vt}")
-        e("v_mov_b32 {vx}, " + L("dist_rev") + "-" + L("base"))
+        if DIRECT8:
+            # (offset << 8) | n.  Slots >= 14: n = (slot >> 1) - 5 direct bits, offset = chain 0's end minus n bit blocks; below 14:
+            # n = 0 and the offset of chain 0's trampoline to dist_rev / dist_small (the jump adds clz chains: every chain has one)
+            e("v_add_u32 {vb}, -5, {VT1}")                 # n
+            e("v_mul_u32_u24 {vt}, (" + L("db_e") + "-" + L("db_s") + "), {vb}")
+            e("v_sub_u32 {tbl_b}, " + L("dend0") + "-" + L("base") + ", {vt}")
+            e("v_lshl_or_b32 {tbl_b}, {tbl_b}, 8, {vb}")
+        else:
+            e("v_sub_u32 {vt}, 31, {VT1}")                     # 26 - count
+            e("v_mul_u32_u24 {vt}, " + bs + ", {vt}")
+            e("v_add_u32 {tbl_b}, " + L("direct_chain") + "-" + L("base") + ", {vt}")
+        rev, small = ("dtr_rev0", "dtr_small0") if DIRECT8 else ("dist_rev", "dist_small")
+        sh = "*256" if DIRECT8 else ""
+        e("v_mov_b32 {vx}, (" + L(rev) + "-" + L("base") + ")" + sh)
         e("v_cmp_gt_u32 vcc, 14, {VT0}")
         e("s_nop 0")
         e("s_nop 0")
         e("v_cndmask_b32 {tbl_b}, {tbl_b}, {vx}, vcc")
-        e("v_mov_b32 {vx}, " + L("dist_small") + "-" + L("base"))
+        e("v_mov_b32 {vx}, (" + L(small) + "-" + L("base") + ")" + sh)
         e("v_cmp_gt_u32 vcc, 4, {VT0}")
         e("s_nop 0")
         e("s_nop 0")
@@ -965,16 +1004,53 @@ class Gen:
         self.tree_walk(V["VPS"], 6, first_lane="1")
         self.tree_update(V["VPS"], 6, defer=True)            # (queued: emitted in the shadows of the align walk; the tree goes
         e("v_readlane_b32 {t2}, {tbl_a}, {sym}")             #  back to its register once it is complete: posslot_writeback)
-        e("v_readlane_b32 {t3}, {tbl_b}, {sym}")
-        e("s_mov_b32 {t4}, 0")
+        if DIRECT8:
+            # entry = offset + ((n + clz) & 7) * chain size - ((n + clz) >> 3) * normalisation size, for every lane
+            e("s_flbit_i32_b32 {t6}, {range}")               # leading zeros of range: 0..7
+            e("v_add_u32 {VT0}, {t6}, {tbl_b}")
+            e("v_and_b32 {VT1}, 7, {VT0}")
+            e("v_bfe_u32 {VT2}, {VT0}, 3, 3")
+            e("v_lshrrev_b32 {VT0}, 8, {VT0}")
+            e("v_mul_u32_u24 {VT1}, (" + L("dend1") + "-" + L("dend0") + "), {VT1}")
+            e("v_mul_u32_u24 {VT2}, (" + L("dn_e") + "-" + L("dn_s") + "), {VT2}")
+            e("v_add_u32 {VT0}, {VT0}, {VT1}")
+            e("v_sub_u32 {VT0}, {VT0}, {VT2}")
+            e("s_mov_b32 {t4}, 0")
+            e("v_readlane_b32 {t3}, {VT0}, {sym}")
+        else:
+            e("v_readlane_b32 {t3}, {tbl_b}, {sym}")
+            e("s_mov_b32 {t4}, 0")
         e("s_add_u32 " + JPAIR_LO + ", {jb_lo}, {t3}")
         e("s_addc_u32 " + JPAIR_HI + ", {jb_hi}, 0")
-        for name in ("direct_chain", "dist_small", "dist_rev"):   # the computed jump's targets arrive with what is queued here
+        targets = ["dist_small", "dist_rev"] + (["dchain%d" % v for v in range(8)] + ["dtr_small%d" % v for v in range(8)] +
+                                                ["dtr_rev%d" % v for v in range(8)] if DIRECT8 else ["direct_chain"])
+        for name in targets:   # the computed jump's targets arrive with what is queued here
             self.lstate[name] = self._st()
         e("s_setpc_b64 " + JPAIR)
-        lab("direct_chain")
-        for _ in range(26):
-            self.direct_bit(R("t4"))
+        if DIRECT8:
+            for v in range(8):
+                lab("dchain%d" % v)
+                if v >= 2:                                   # (every chain carries four normalisation blocks, so that they are all
+                    self.direct_norm()                       #  the same size: this one is never reached)
+                for r in range(25, -1, -1):                  # r = direct bits left after this one
+                    mark = v == 0 and r == 25
+                    if mark:
+                        lab("db_s")
+                    self.direct_bit(R("t4"), test=False)
+                    if mark:
+                        lab("db_e")
+                    if r % 8 == v:
+                        self.direct_norm(mark="dn" if (v == 0 and r == 24) else None)
+                lab("dend%d" % v)
+                e("s_branch " + L("direct_done"))
+                lab("dtr_small%d" % v)                       # slots below 14 land here (no direct bits; chain = clz)
+                e("s_branch " + L("dist_small"))
+                lab("dtr_rev%d" % v)
+                e("s_branch " + L("dist_rev"))
+        else:
+            lab("direct_chain")
+            for _ in range(26):
+                self.direct_bit(R("t4"))
         lab("direct_done")
         self.tree_walk(R("m_align"), 4, first_lane="1")
         self.posslot_writeback()
