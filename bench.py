@@ -239,6 +239,44 @@ def cpu_baseline(size, kind, dict_size, cores):
 
 
 
+def issue_roofline(config, kind, out_bytes, k_ms, khash):
+    """The decode kernel against the measured instruction-issue ceiling of its own decision chain (what binds it), from the exact
+    executed-instruction mix of this workload (tools/emu/profile.py over 16 streams); None if the recorded mix belongs to
+    another kernel source or workload."""
+    mix_path = os.path.join(ROOT, "profiles", "r03_instruction_mix_%s.json" % config)
+    if kind != "text" or not os.path.exists(mix_path):
+        return None
+    with open(mix_path) as f:
+        mix = json.load(f)
+    if mix.get("kernel_source_sha256") != khash:
+        return None
+    pb = mix["per_output_byte"]
+    s_rate = pb["salu"] * out_bytes / (k_ms * 1e-3)
+    i_rate = pb["total"] * out_bytes / (k_ms * 1e-3)
+    return {"bound": "instruction_issue", "achieved": round(i_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * CHAIN_IPC, 1),
+            "unit": "G instructions/s", "frac": round(i_rate / 1e9 / (CUS * CLOCK_GHZ * CHAIN_IPC), 4),
+            "instructions_per_output_byte": pb["total"], "salu_per_output_byte": pb["salu"],
+            "valu_per_output_byte": pb["valu"], "branch_per_output_byte": pb["branch"],
+            "scalar_only": {"achieved": round(s_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * SALU_IPC, 1),
+                            "frac": round(s_rate / 1e9 / (CUS * CLOCK_GHZ * SALU_IPC), 4)},
+            "note": "the peak is a MEASURED ceiling of this kernel's own decision chain at the occupancy 4096 streams give (4 waves per "
+                    "SIMD: 1.71 instructions per cycle per CU; experiments/microbench/chain_latency.hip, profiles/r02_chain_latency.txt), "
+                    "not a data-sheet number and not what the hardware can issue: the same chain reaches 2.42 at 8 waves per SIMD, which "
+                    "would need 8192 streams and <= 64 VGPRs.  frac ~ 1 says the kernel runs as fast as its instruction stream can be "
+                    "issued one wave per stream; only a shorter stream makes it faster.  Instruction counts: exact, the kernel's symbol "
+                    "loop executed in tools/emu on 16 streams of this workload (" + os.path.basename(mix_path) + ")"}
+
+
+def pmc_traffic(config, khash):
+    """HBM bytes per launch from the recorded PMC passes of this kernel source (profiles/r03_pmc_<config>.json), else None"""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % config)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    return pmc["derived"]["hbm_bytes_per_launch"] if pmc.get("kernel_source_sha256") == khash else None
+
+
 def tile_units(M, units_d, blob_len, n, distinct, upi, size):
     """tile the distinct items over the n slots (each slot still reads its own copy from HBM).
     Returns (units ctypes array, compressed payload bytes of the tiled batch)."""
@@ -336,7 +374,9 @@ def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
             "ms_per_step": round(step_s * 1e3, 3), "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
             "bit_exact": bad == 0, "verified_units": verified, "distinct_items": distinct, "generation_s": round(gen_s, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg}}
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg,
+                         "traffic": pmc_traffic(name, kernel_source_hash())},
+            "roofline_issue": issue_roofline(name, "text", out_bytes, k_ms, kernel_source_hash())}
 
 
 def run_inproc(args):
@@ -682,7 +722,7 @@ def main():
     k_ms = statistics.median(kernel_ms)
     khash = kernel_source_hash()
     traffic, traffic_note = None, "no PMC pass recorded for this kernel source and workload"
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.config)
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.config)
     if os.path.exists(pmc_path) and args.kind == "text" and (n, size, dict_size) == (cfg["streams"], cfg["size"], cfg["dict"]):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -690,29 +730,10 @@ def main():
             traffic = pmc["derived"]["hbm_bytes_per_launch"]
             traffic_note = pmc["derived"]["traffic_note"]
         else:
-            traffic_note = "profiles/r02_pmc_%s.json was taken with another kernel source (%s)" % (args.config, pmc.get("kernel_source_sha256"))
+            traffic_note = "profiles/r03_pmc_%s.json was taken with another kernel source (%s)" % (args.config, pmc.get("kernel_source_sha256"))
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    scalar = None
-    mix_path = os.path.join(ROOT, "profiles", "r02_instruction_mix.json")
-    if os.path.exists(mix_path) and args.config == "lzma64k" and args.kind == "text":
-        with open(mix_path) as f:
-            mix = json.load(f)
-        if mix.get("kernel_source_sha256") == khash:
-            pb = mix["per_output_byte"]
-            s_rate = pb["salu"] * out_bytes_rank / (k_ms * 1e-3)
-            i_rate = pb["total"] * out_bytes_rank / (k_ms * 1e-3)
-            scalar = {"bound": "instruction_issue", "achieved": round(i_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * CHAIN_IPC, 1),
-                      "unit": "G instructions/s", "frac": round(i_rate / 1e9 / (CUS * CLOCK_GHZ * CHAIN_IPC), 4),
-                      "instructions_per_output_byte": pb["total"], "salu_per_output_byte": pb["salu"],
-                      "valu_per_output_byte": pb["valu"], "branch_per_output_byte": pb["branch"],
-                      "scalar_only": {"achieved": round(s_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * SALU_IPC, 1),
-                                      "frac": round(s_rate / 1e9 / (CUS * CLOCK_GHZ * SALU_IPC), 4)},
-                      "note": "peaks are MEASURED ceilings, not data-sheet numbers (experiments/microbench/chain_latency.hip, "
-                              "profiles/r02_chain_latency.txt, 16 waves per CU): a chain of dependent scalar instructions issues 1.72 per "
-                              "cycle per CU, the decision chain of this kernel (scalar + vector + v_readlane hop) 1.71 instructions per "
-                              "cycle per CU; instruction counts: exact, from executing the kernel's symbol loop in tools/emu on one "
-                              "stream of this workload (profiles/r02_instruction_mix.json)"}
+    scalar = issue_roofline(args.config, args.kind, out_bytes_rank, k_ms, khash)
 
     if rank == 0:
         what = ("%d .xz files of %d B per GPU (1 MiB blocks, LZMA2 with stored chunks, CRC64): %d LZMA2 units" % (n, size, n_units)

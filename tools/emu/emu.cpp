@@ -47,7 +47,7 @@ struct Ins {
   X(v_mul_u32_u24) X(v_mad_u32_u24) X(v_mul_lo_u32) X(v_cndmask_b32) X(v_cmp_lt_u32) X(v_cmp_eq_u32) X(v_cmp_gt_u32)   \
   X(v_cmp_ge_u32) X(v_cmp_le_u32) X(v_cmp_ne_u32) X(v_lshl_or_b32) X(v_lshl_add_u32) X(v_add_lshl_u32)                 \
   X(v_and_or_b32) X(v_add3_u32) X(v_bfe_u32) X(v_ffbh_u32) X(v_cvt_f32_u32) X(v_cvt_u32_f32) X(v_rcp_f32)              \
-  X(v_add_f32) X(v_mul_f32) X(v_min_u32) X(v_max_u32) X(v_movrels_b32) X(v_movreld_b32) X(v_bfi_b32)                   \
+  X(v_add_f32) X(v_mul_f32) X(v_min_u32) X(v_max_u32) X(v_max_i32) X(v_movrels_b32) X(v_movreld_b32) X(v_bfi_b32)                   \
   X(v_alignbit_b32) X(v_or3_b32) X(v_xad_u32) X(v_sub_co_u32) X(v_mbcnt_lo_u32_b32) X(v_mbcnt_hi_u32_b32)              \
   X(ds_read_b128) X(ds_write_b128) X(ds_read_b32) X(ds_write_b32) X(ds_read_u8) X(ds_write_b8) X(ds_read_b64)          \
   X(ds_write_b64) X(buffer_load_ubyte) X(buffer_store_byte) X(buffer_load_dword) X(buffer_store_dword)                 \
@@ -318,6 +318,7 @@ long run(Emu& e, int start, long max_steps) {
       case OP_v_xor_b32: vop2(e, I, [](uint32_t a, uint32_t b) { return a ^ b; }); break;
       case OP_v_min_u32: vop2(e, I, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); break;
       case OP_v_max_u32: vop2(e, I, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); break;
+      case OP_v_max_i32: vop2(e, I, [](uint32_t a, uint32_t b) { return uint32_t(int32_t(a) > int32_t(b) ? int32_t(a) : int32_t(b)); }); break;
       case OP_v_mul_u32_u24: vop2(e, I, [](uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }); break;
       case OP_v_mul_lo_u32: vop2(e, I, [](uint32_t a, uint32_t b) { return a * b; }); break;
       case OP_v_mad_u32_u24: vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }); break;

@@ -101,6 +101,10 @@ NORM64 = os.environ.get("MILZMA_GEN_NORM64", "1") == "1"
 # unconditional inline normalisations at fixed places and 4-instruction bit blocks; the entry address is computed per lane on the
 # vector ALU from tbl_b and clz and fetched with the one v_readlane that fetched the table entry before.
 DIRECT8 = os.environ.get("MILZMA_GEN_DIRECT8", "1") == "1"
+# The state after a literal (lzma.rs:472-478) from a per-lane table with one v_readlane instead of two / three scalar instructions
+# (verdict item 1a: "state transition by table"); the v_readlane sits in front of the literal walk's vector instructions, so the
+# vector -> scalar hop it starts is over before the next scalar instruction wants to issue.
+STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
 if "1" in NORM_S:
@@ -120,7 +124,7 @@ RET = "s[92:93]"  # return address of the window refill subroutine
 _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt=93, VR=94, VL16=95, VOOB=96, VKTOP=97, vx=98,
            VLANE64=99, VLANE128=100, VLANE192=101, vb=102, VSH6=103, VSH6M1=104, VSH5=105, VSH5M1=106, VSH4=107, VSH4M1=108,
            VLEVEL=109, va=110, vr=112, VLANEM1=113,
-           DVT=114, DVA=115, DVX=116, c2017=117, c2048=118)  # temporaries of deferred updates; the constants 2017 and 2048
+           DVT=114, DVA=115, DVX=116, c2017=117, c2048=118, VSTT=119)  # temporaries of deferred updates; the constants 2017 and 2048
 if PAD_V:
     _V0["vpad"] = 111
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE = {}, "", "", "", [], 16, None
@@ -366,7 +370,7 @@ class Gen:
             self.e("v_readlane_b32 {range}, {vb}, {ln}", ln=ln)      # (bound, code)
             self.e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)        # range - bound
             self.shadow(SHADOW)
-            self.flush_reads(vcc=True)
+            self.flush_reads(vcc=True, sym=True)     # (the caller may extend sym right after the decision)
             mask()
             self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
@@ -383,7 +387,7 @@ class Gen:
             self.shadow(1)
             self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
             self.shadow(SHADOW - 1)
-            self.flush_reads(vcc=True)
+            self.flush_reads(vcc=True, sym=True)
             mask()
         else:
             mask()
@@ -1110,6 +1114,14 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        if STATE_TBL:   # lane = state: 0 below 4, state - 3 up to 9, state - 6 from 10 on
+            e("v_add_u32 {VSTT}, -3, {v_lane}")
+            e("v_max_i32 {VSTT}, 0, {VSTT}")
+            e("v_add_u32 {vx}, -6, {v_lane}")
+            e("v_cmp_gt_u32 vcc, 10, {v_lane}")
+            e("s_nop 0")
+            e("s_nop 0")
+            e("v_cndmask_b32 {VSTT}, {vx}, {VSTT}, vcc")
         self.set_guards(R("n0"))
         self.tables_prologue()
         if PRIO:
@@ -1136,8 +1148,11 @@ class Gen:
         self.symbol_top("L")
         # ---- plain literal (lzma.rs:526-561)
         self.literal_row("L")
-        e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
-        e("s_max_i32 {state}, {state}, 0")
+        if STATE_TBL:
+            e("v_readlane_b32 {state}, {VSTT}, {state}")     # state after a literal (lzma.rs:472-478)
+        else:
+            e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
+            e("s_max_i32 {state}, {state}, 0")
         self.tree_walk(R("u0"), 6, first_lane="1")  # nodes 1..63 -> u0
         self.tree_update(R("u0"), 6, defer=True)   # (queued: emitted in the shadows of levels 6 and 7)
         self.literal_tail(False)
@@ -1181,9 +1196,12 @@ class Gen:
         self.finish_pending(have_t6=True, prof="m")
         lab("lit_pM")
         self.literal_row("M")
-        e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
-        e("s_cselect_b32 {t1}, 3, 6")
-        e("s_sub_u32 {state}, {state}, {t1}")
+        if STATE_TBL:
+            e("v_readlane_b32 {state}, {VSTT}, {state}")     # states 7..11 -> 4, 5, 6, 4, 5
+        else:
+            e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
+            e("s_cselect_b32 {t1}, 3, 6")
+            e("s_sub_u32 {state}, {state}, {t1}")
         e("s_add_u32 {t0}, {rep0}, 1")
         e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
         e("s_cmp_gt_u32 {t0}, {dict_size}")

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 --pmc passes of one bench workload into profiles/r03_pmc_<config>.json (what bench.py's
+roofline.traffic reads, keyed by the kernel source hash).
+
+    python tools/make_pmc_profile.py <config> <dir with pass_*/**/*counter_collection.csv> <out.json>
+
+FETCH_SIZE is doubled (128-byte requests tallied at 64: MI355X_MICROARCH.md, re-calibrated on this kernel's byte loads with
+experiments/pmc_calib.hip in round 2: profiles/r02_pmc_lzma64k.json `calibration`); WRITE_SIZE is exact for byte stores."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    config, src, out = sys.argv[1:4]
+    key = "decode_fast_asm_kernel"
+    counters, dur, passes = {}, [], {}
+    for path in sorted(glob.glob(os.path.join(src, "pass_*", "**", "*counter_collection.csv"), recursive=True)):
+        per = defaultdict(lambda: defaultdict(float))
+        for r in csv.DictReader(open(path)):
+            if key not in r["Kernel_Name"]:
+                continue
+            per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        if not per:
+            continue
+        name = path[len(src):].strip("/").split("/")[0]
+        passes[name] = len(per)
+        for c in sorted({c for d in per.values() for c in d}):
+            counters[c] = sum(d.get(c, 0.0) for d in per.values()) / len(per)
+    cfg = bench.CONFIGS[config]
+    out_bytes = cfg["streams"] * cfg["size"]
+    derived = {}
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        fetch = counters["FETCH_SIZE"] * 1024 * 2
+        write = counters["WRITE_SIZE"] * 1024
+        derived = {"fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+                   "output_bytes_per_launch": out_bytes,
+                   "traffic_note": "rocprofv3 FETCH_SIZE x 2 (128-B requests tallied at 64 B; calibrated on byte loads, "
+                                   "profiles/r02_pmc_lzma64k.json) + WRITE_SIZE (exact for byte stores), separate --pmc passes of this "
+                                   "kernel source on the bench's own batch (%d distinct streams tiled over %d).  Writes = the output, "
+                                   "once; reads = one 128-B line of the stream's own LZ77 window per match from beyond the XCD's "
+                                   "4 MiB L2 plus the compressed input: byte-granular dictionary reads, ~3 %% of the HBM roofline"
+                                   % (cfg["distinct"], cfg["streams"])}
+    for k in ("SQ_INSTS_SALU", "SQ_INSTS_VALU"):
+        if k in counters:
+            derived[k.lower() + "_per_output_byte"] = counters[k] / out_bytes
+    with open(out, "w") as f:
+        json.dump({"kernel_source_sha256": bench.kernel_source_hash(), "config": config,
+                   "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py --config %s "
+                              "--steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none "
+                              "(experiments/gpu_calls/gpu_pmc_r3.sh)" % config,
+                   "dispatches_per_pass": passes, "kernel_ms_under_pmc": round(sum(dur) / max(1, len(dur)), 2),
+                   "counters_per_launch": counters, "derived": derived}, f, indent=1)
+        f.write("\n")
+    print(open(out).read()[:1500])
+
+
+if __name__ == "__main__":
+    main()
