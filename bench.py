@@ -5,7 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--gpus N` without a torchrun environment launches the N ranks itself (one per GPU, 127.0.0.1
-rendezvous) and fails loudly when the node has fewer than N GPUs.
+rendezvous) and fails loudly when the node has fewer than N GPUs.  `--gpus N --inproc` drives the N GPUs
+from ONE process through the library's own multi-device entry point (milzma_multi_decode_units).
+A default 1-GPU run also measures configs[2] and configs[3] after the headline (a few steps each,
+CRC-verified the same way) and attaches them as `other_configs`.
 
 Workloads (BASELINE.json `configs`), all synthetic, compressed with liblzma on the host before the
 timed region, "text" class plaintext (seed 0xC0FFEE ^ i):
@@ -16,8 +19,10 @@ timed region, "text" class plaintext (seed 0xC0FFEE ^ i):
 A step = one call of milzma_decode_units over the whole batch with compressed input and output
 slices resident in HBM (descriptor upload and result download included).  N > 1: every rank decodes
 its own batch (weak scaling), no collective on the data path; time = max over ranks between
-barriers.  `--scatter` additionally ships every rank's compressed input from rank 0 and gathers the
-decoded output back over the process group (RCCL on GPUs), timed separately.
+barriers.  `--scatter`: rank 0 is the node's ingest point -- it holds a pool of N x distinct different
+streams, partitions it by compressed bytes with the library's planner (milzma_partition), ships every rank
+its share device to device over the process group (RCCL on GPUs), and after the decode gathers the
+outputs back and CRC-checks every gathered unit on its GPU; timed separately (`scatter_gather`).
 
 After the timed steps the output buffer is zeroed, one more step runs, and the CRC-32 of EVERY
 unit's output is computed on the GPU (milzma_crc_units) and compared with zlib.crc32 of the
@@ -274,7 +279,7 @@ def pmc_traffic(config, khash):
         return None
     with open(path) as f:
         pmc = json.load(f)
-    return pmc["derived"]["hbm_bytes_per_launch"] if pmc.get("kernel_source_sha256") == khash else None
+    return pmc.get("derived", {}).get("hbm_bytes_per_launch") if pmc.get("kernel_source_sha256") == khash else None
 
 
 def tile_units(M, units_d, blob_len, n, distinct, upi, size):
@@ -726,7 +731,7 @@ def main():
     if os.path.exists(pmc_path) and args.kind == "text" and (n, size, dict_size) == (cfg["streams"], cfg["size"], cfg["dict"]):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if pmc.get("kernel_source_sha256") == khash:
+        if pmc.get("kernel_source_sha256") == khash and "hbm_bytes_per_launch" in pmc.get("derived", {}):
             traffic = pmc["derived"]["hbm_bytes_per_launch"]
             traffic_note = pmc["derived"]["traffic_note"]
         else:
