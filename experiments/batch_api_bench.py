@@ -107,3 +107,27 @@ for ncalls in sorted({2, calls}):
             finish(k)
     dt = time.time() - t0
     print("%d calls x %d files, two in flight: %d ok, %.2f GiB out in %.3f s = %.2f GB/s" % (ncalls, n, ok, total / 2**30, dt, total / dt / 1e9))
+
+
+# ---- ONE call with two chip-fulls of files: the library groups it over the context and its peer ----------------------
+n2 = 2 * n
+ptrs2 = (ctypes.c_void_p * n2)(*([b[0] for b in bufs] * 2))
+lens2 = (ctypes.c_size_t * n2)(*([b[1] for b in bufs] * 2))
+for label, env in (("grouped (default)", None), ("one launch (MILZMA_NO_GROUPS=1)", "1")):
+    if env:
+        os.environ["MILZMA_NO_GROUPS"] = env
+    for rep in range(2):
+        outs2 = (M._COutput * n2)()
+        t0 = time.time()
+        if mode == "lzma":
+            lib.milzma_lzma_decompress_batch(ctx._h, n2, ptrs2, lens2, None, outs2)
+        else:
+            lib.milzma_xz_decompress_batch(ctx._h, n2, ptrs2, lens2, outs2)
+        dt = time.time() - t0
+        total = sum(outs2[i].len for i in range(n2))
+        ok = sum(1 for i in range(n2) if outs2[i].kind == 0)
+        for i in range(n2):
+            if outs2[i].data:
+                lib.milzma_free(ctypes.cast(outs2[i].data, ctypes.c_void_p))
+    print("one call x %d files, %s: %d ok, %.2f GiB out in %.3f s = %.2f GB/s" % (n2, label, ok, total / 2**30, dt, total / dt / 1e9))
+os.environ.pop("MILZMA_NO_GROUPS", None)

@@ -71,6 +71,7 @@ struct milzma_ctx {
   std::thread batch_thread;
   bool batch_pending = false;
   int batch_rc = 0;
+  milzma_ctx* peer = nullptr;  // a second context on the same device: large whole-file calls alternate their groups between the two
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
   int order_mode = 0;    // MILZMA_ORDER: 0 sorted by input length (default), 1 stride, 2 shuffle (tuning)
@@ -260,6 +261,8 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
 extern "C" void milzma_destroy(milzma_ctx* ctx) {
   if (!ctx) return;
   if (ctx->batch_thread.joinable()) ctx->batch_thread.join();
+  if (ctx->peer) milzma_destroy(ctx->peer);
+  ctx->peer = nullptr;
   (void)hipSetDevice(ctx->device);
   dev_release(ctx->units);
   dev_release(ctx->order);
@@ -1828,10 +1831,73 @@ extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_
   }
 }
 
+// A call with at least two chip-fulls of work is cut into groups of >= kGroupUnits decode units (whole files) that alternate between
+// the context and a peer context on the same device, each group on its own host thread: the upload of group k + 1 and the download +
+// hand-over of group k - 1 run under group k's kernel (one group alone cannot overlap its own three phases: every stream takes the
+// whole kernel).  units_of(i): decode units file i contributes (1 per stream, blocks per .xz file).
+namespace {
+
+constexpr uint32_t kGroupUnits = 4096;
+
+template <class Units, class Call>
+int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, milzma_output* outs, Units units_of,
+                  Call call) {
+  std::vector<uint32_t> cut{0};
+  if (ctx && n && ins && in_lens && !getenv("MILZMA_NO_GROUPS")) {
+    uint64_t total = 0, acc = 0;
+    std::vector<uint32_t> u(n);
+    for (uint32_t i = 0; i < n; i++) total += (u[i] = units_of(i));
+    if (total >= 2 * uint64_t(kGroupUnits)) {
+      const uint64_t groups = total / kGroupUnits, per = (total + groups - 1) / groups;  // equal groups, each a full chip or more
+      for (uint32_t i = 0; i < n; i++) {
+        acc += u[i];
+        if (acc >= per && i + 1 < n && total - acc >= kGroupUnits / 2) {
+          cut.push_back(i + 1);
+          total -= acc;
+          acc = 0;
+        }
+      }
+    }
+  }
+  cut.push_back(n);
+  if (cut.size() <= 2) return call(ctx, n, ins, in_lens, outs);
+  if (!ctx->peer && milzma_create(ctx->device, &ctx->peer) != MILZMA_OK) return call(ctx, n, ins, in_lens, outs);
+  milzma_ctx* lane[2] = {ctx, ctx->peer};
+  std::thread th[2];
+  int rc[2] = {MILZMA_OK, MILZMA_OK}, worst = MILZMA_OK;
+  for (size_t g = 0; g + 1 < cut.size(); g++) {
+    const int k = int(g & 1);
+    if (th[k].joinable()) {
+      th[k].join();
+      if (rc[k] != MILZMA_OK) worst = rc[k];
+    }
+    const uint32_t lo = cut[g], m = cut[g + 1] - cut[g];
+    th[k] = std::thread([&, k, lo, m] { rc[k] = call(lane[k], m, ins + lo, in_lens + lo, outs + lo); });
+  }
+  for (int k = 0; k < 2; k++)
+    if (th[k].joinable()) {
+      th[k].join();
+      if (rc[k] != MILZMA_OK) worst = rc[k];
+    }
+  if (worst != MILZMA_OK && ctx->peer && !ctx->peer->err.empty() && ctx->err.empty()) ctx->err = ctx->peer->err;
+  return worst;
+}
+
+uint32_t xz_units_of(const uint8_t* in, size_t n) {
+  std::vector<PlannedBlock> blocks;
+  return plan_from_index(in, n, &blocks) && !blocks.empty() ? uint32_t(blocks.size()) : 1u;
+}
+
+}  // namespace
+
 extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                             const milzma_options* opt, milzma_output* outs) {
   try {
-    return milzma_lzma_decompress_batch_impl(ctx, n, ins, in_lens, opt, outs);
+    return grouped_batch(
+        ctx, n, ins, in_lens, outs, [](uint32_t) { return 1u; },
+        [opt](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+          return milzma_lzma_decompress_batch_impl(c, k, i, l, opt, o);
+        });
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
     if (ctx) ctx->err = std::string("host exception: ") + e.what();
     for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
@@ -1842,7 +1908,11 @@ extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const u
 extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                              milzma_output* outs) {
   try {
-    return milzma_lzma2_decompress_batch_impl(ctx, n, ins, in_lens, outs);
+    return grouped_batch(
+        ctx, n, ins, in_lens, outs, [](uint32_t) { return 1u; },
+        [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+          return milzma_lzma2_decompress_batch_impl(c, k, i, l, o);
+        });
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
     if (ctx) ctx->err = std::string("host exception: ") + e.what();
     for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
@@ -1853,7 +1923,11 @@ extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const 
 extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                           milzma_output* outs) {
   try {
-    return milzma_xz_decompress_batch_impl(ctx, n, ins, in_lens, outs);
+    return grouped_batch(
+        ctx, n, ins, in_lens, outs, [&](uint32_t i) { return xz_units_of(ins[i], in_lens[i]); },
+        [](milzma_ctx* c, uint32_t k, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+          return milzma_xz_decompress_batch_impl(c, k, i, l, o);
+        });
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
     if (ctx) ctx->err = std::string("host exception: ") + e.what();
     for (uint32_t i = 0; i < n; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());

@@ -793,3 +793,21 @@ def test_whole_file_batches_async_two_in_flight(ctx):
             assert x.ok and x.data == p
     finally:
         other.close()
+
+
+def test_large_batch_calls_are_grouped_over_two_contexts(ctx):
+    """>= 8192 decode units in one whole-file call: the library cuts it into chip-sized groups that alternate between the context and
+    a peer context (uploads / downloads of one group under the other's kernel).  Same results as small calls, every file in place."""
+    plains = [W.make_plain("text" if i % 3 else "random", 200 + (i * 37) % 900, seed=i) for i in range(64)]
+    comps = [W.compress_alone(p, dict_size=1 << 12, known_size=(i % 2 == 0)) for i, p in enumerate(plains)]
+    comps[7] = comps[7][:30]                                     # a truncated one in every 64
+    files = [comps[i % 64] for i in range(8300)]
+    decs = ctx.lzma_batch(files)
+    ref = [orc.lzma_decompress(c) for c in comps]
+    for i, d in enumerate(decs):
+        r = ref[i % 64]
+        assert (d.kind, d.msg, d.data) == (r.kind, r.msg, r.out), i
+    xz = [lzma.compress(p * 3, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32) for p in plains[:32]]
+    many = [xz[i % 32] for i in range(8200)]
+    for i, d in enumerate(ctx.xz_batch(many)):
+        assert d.ok and d.data == plains[i % 32] * 3, i
