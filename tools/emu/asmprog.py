@@ -356,7 +356,8 @@ class AsmLoop:
             if n < 0:
                 raise RuntimeError("emulator: " + self.L.emu_error(self.h).decode())
             executed += n
-            ex = self.sget("exitcode")
+            ex = self.sget("exitcode") & 0xFF      # (bit 8: "re-seek before reading on" -- positions are right either way)
+            S("exitcode", ex)
             if ex != G.EXIT["LZ_SLOW"]:
                 break
             # append_lz_slow: matches of >= 64 bytes or running into the output limit
@@ -386,7 +387,7 @@ class AsmLoop:
             elif name == "DONE_FIN":
                 status = ST_OK
             elif name == "MARKER":
-                rem = self.sget("lim") - self.sget("off")
+                rem = (self.sget("lim") - self.sget("off")) & 0xFFFFFFFF
                 status = ST_OK if (rem == 0 and self.sget("code") == 0) else "MARKER_TRAILING"
                 if status == ST_OK and known and ln != unpacked_size:   # lzma.rs:513-521 applies after the marker too
                     status = "SIZE_MISMATCH"
@@ -394,7 +395,7 @@ class AsmLoop:
                 status = "OUT_FULL"
             else:
                 status = name
-        in_consumed = self.sget("wbase") + self.sget("off")
+        in_consumed = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF   # (an end-aligned last window may start "before" 0)
         if status == ST_INPUT_EOF:
             in_consumed = in_len
         return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,

@@ -104,6 +104,14 @@ DIRECT8 = os.environ.get("MILZMA_GEN_DIRECT8", "1") == "1"
 # The state after a literal (lzma.rs:472-478) from a per-lane table with one v_readlane instead of two / three scalar instructions
 # (verdict item 1a: "state transition by table"); the v_readlane sits in front of the literal walk's vector instructions, so the
 # vector -> scalar hop it starts is over before the next scalar instruction wants to issue.
+# `off` (lane of the next input byte) and `lim` are kept biased by -64 inside the loop: the increment after a byte then carries out exactly
+# when the window is used up, and the carry is the refill test (no s_bitcmp); v_readlane takes the lane from the low 6 bits either way.
+OFFBIAS = os.environ.get("MILZMA_GEN_OFFBIAS", "1") == "1"
+# EOFWRAP (needs OFFBIAS): the last window of the input is loaded END-aligned (its lane 63 is the last byte), so that "window used up"
+# and "reader at EOF" are the same carry: the normalisation stubs lose their `off == lim` test.  lim (biased) = bytes beyond the
+# current window; -1 = nothing left at all (then off = -1: the next byte asked for carries at once and is the EOF error).
+# Invariant everywhere: reader position = wbase + 64 + off (biased).
+EOFWRAP = OFFBIAS and os.environ.get("MILZMA_GEN_EOFWRAP", "1") == "1"
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
@@ -327,8 +335,9 @@ class Gen:
             self.e("s_branch " + self.L(to))
         with Gen._Into(self, self.stubs):
             self.lab(k)
-            self.e("s_cmp_eq_u32 {off}, {lim}")
-            self.e("s_cbranch_scc1 " + self.L("Xeof"))
+            if not EOFWRAP:
+                self.e("s_cmp_eq_u32 {off}, {lim}")
+                self.e("s_cbranch_scc1 " + self.L("Xeof"))
             self.e("v_readlane_b32 {n1}, {winb}, {off}")
             if NORM64:   # range < 2^24 here: its top byte is zero, so one 64-bit shift of the (range, code) pair moves both
                 self.e("s_lshl_b64 " + RC + ", " + RC + ", 8")
@@ -337,7 +346,8 @@ class Gen:
                 self.e("s_lshl_b32 {code}, {code}, 8")
             self.e("s_or_b32 {code}, {code}, {n1}")
             self.e("s_add_u32 {off}, {off}, 1")
-            self.e("s_bitcmp1_b32 {off}, 6")
+            if not OFFBIAS:
+                self.e("s_bitcmp1_b32 {off}, 6")
             self.e("s_cbranch_scc0 " + self.L(ret))
             self.e("s_call_b64 " + RET + ", " + self.L("refill"))
             self.e("s_branch " + self.L(ret))
@@ -574,13 +584,15 @@ class Gen:
         k = self.new("DN")
         if mark:
             self.lab(mark + "_s")
-        e("s_cmp_eq_u32 {off}, {lim}")
-        e("s_cbranch_scc1 " + L("Xeof"))
+        if not EOFWRAP:
+            e("s_cmp_eq_u32 {off}, {lim}")
+            e("s_cbranch_scc1 " + L("Xeof"))
         e("v_readlane_b32 {n1}, {winb}, {off}")
         e("s_lshl_b64 " + RC + ", " + RC + ", 8")
         e("s_or_b32 {code}, {code}, {n1}")
         e("s_add_u32 {off}, {off}, 1")
-        e("s_bitcmp1_b32 {off}, 6")
+        if not OFFBIAS:
+            e("s_bitcmp1_b32 {off}, 6")
         e("s_cbranch_scc1 " + L(k))
         if mark:
             self.lab(mark + "_e")
@@ -623,7 +635,15 @@ class Gen:
         e = self.e
         e("s_add_u32 {t}, {safe_len}, 1", t=t)
         e("s_min_u32 {gtop}, {target}, {t}", t=t)
-        e("s_cmpk_gt_u32 {lim}, 63")
+        # gtop = 0 (every symbol looks closer) while the reader may be at EOF before the symbol ends.  (lim is a u32 of up to 4 GiB:
+        # no signed compares on it)
+        if EOFWRAP:
+            e("s_cmp_lg_u32 {lim}, -1")                     # -1: the reader IS at EOF
+        elif OFFBIAS:
+            e("s_add_u32 {t}, {lim}, 64", t=t)
+            e("s_cmpk_gt_u32 {t}, 63", t=t)
+        else:
+            e("s_cmpk_gt_u32 {lim}, 63")                    # more than this window left
         e("s_cselect_b32 {gtop}, {gtop}, 0")
         e("s_min_u32 {gdist}, {len}, {dict_size}")          # a lower bound of min(len, dict_size): len only grows
         e("s_cmpk_ge_u32 {mlen}, 64")
@@ -1114,6 +1134,42 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        if EOFWRAP:      # from the C++ side's reader (aligned windows, off = lane, EOF at lane lim) to the loop's (undone in finish())
+            e("s_cmpk_lt_u32 {lim}, 64")
+            e("s_cbranch_scc1 " + L("Oentry_last"))
+            e("s_add_u32 {off}, {off}, -64")
+            e("s_add_u32 {lim}, {lim}, -64")
+            e("s_add_u32 {n0}, {lim}, -1")
+            e("s_cmpk_lt_u32 {n0}, 63")                      # 1..63 bytes beyond this window: the prefetched window must be the
+            e("s_cbranch_scc1 " + L("Oentry_pref"))          # end-aligned one
+            lab("entry_ok")
+            with self.in_cold():
+                lab("Oentry_pref")
+                e("s_add_u32 {n0}, {wbase}, {lim}")
+                e("v_add_u32 {VR}, {n0}, {v_lane}")
+                e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
+                e("s_branch " + L("entry_ok"))
+                lab("Oentry_last")                           # EOF inside the current window
+                e("s_sub_u32 {n0}, {lim}, {off}")            # bytes left
+                e("s_cmp_eq_u32 {n0}, 0")
+                e("s_cbranch_scc1 " + L("Oentry_eof"))
+                e("s_add_u32 {wbase}, {wbase}, {lim}")       # reload it end-aligned
+                e("s_add_u32 {wbase}, {wbase}, -64")
+                e("v_add_u32 {VR}, {wbase}, {v_lane}")
+                e("buffer_load_ubyte {winb}, {VR}, {in_rsrc}, 0 offen")
+                e("s_waitcnt vmcnt(0)")
+                e("s_sub_u32 {off}, 0, {n0}")
+                e("s_mov_b32 {lim}, 0")
+                e("s_branch " + L("entry_ok"))
+                lab("Oentry_eof")
+                e("s_add_u32 {wbase}, {wbase}, {off}")
+                e("s_add_u32 {wbase}, {wbase}, -63")
+                e("s_mov_b32 {off}, -1")
+                e("s_mov_b32 {lim}, -1")
+                e("s_branch " + L("entry_ok"))
+        elif OFFBIAS:      # (undone in finish(): outside the loop off is the lane, 0..63)
+            e("s_add_u32 {off}, {off}, -64")
+            e("s_add_u32 {lim}, {lim}, -64")
         if STATE_TBL:   # lane = state: 0 below 4, state - 3 up to 9, state - 6 from 10 on
             e("v_add_u32 {VSTT}, -3, {v_lane}")
             e("v_max_i32 {VSTT}, 0, {VSTT}")
@@ -1379,13 +1435,27 @@ class Gen:
             e("s_branch " + L("cp_a"))
 
             lab("refill")                                     # subroutine: the window's 64 bytes are used up
-            e("s_waitcnt vmcnt(0)")
-            e("v_mov_b32 {winb}, {winb_next}")
-            e("s_add_u32 {wbase}, {wbase}, 64")
-            e("s_mov_b32 {off}, 0")
-            e("s_sub_u32 {lim}, {lim}, 64")
-            self.set_guards(R("n0"))
-            e("s_add_u32 {n0}, {wbase}, 64")
+            if EOFWRAP:
+                e("s_add_u32 {n0}, {lim}, 1")                 # lim is 0 (nothing beyond this window: the reader is at EOF now) or -1
+                e("s_cmpk_lt_u32 {n0}, 2")                    # (it was already)
+                e("s_cbranch_scc1 " + L("Orefill_end"))
+                e("s_waitcnt vmcnt(0)")
+                e("v_mov_b32 {winb}, {winb_next}")
+                e("s_min_u32 {n1}, {lim}, 64")                # the next window: 64 bytes, or the last ones end-aligned
+                e("s_add_u32 {wbase}, {wbase}, {n1}")
+                e("s_sub_u32 {off}, 0, {n1}")
+                e("s_sub_u32 {lim}, {lim}, {n1}")
+                self.set_guards(R("n0"))
+                e("s_min_u32 {n1}, {lim}, 64")
+                e("s_add_u32 {n0}, {wbase}, {n1}")
+            else:
+                e("s_waitcnt vmcnt(0)")
+                e("v_mov_b32 {winb}, {winb_next}")
+                e("s_add_u32 {wbase}, {wbase}, 64")
+                e("s_mov_b32 {off}, -64" if OFFBIAS else "s_mov_b32 {off}, 0")
+                e("s_sub_u32 {lim}, {lim}, 64")
+                self.set_guards(R("n0"))
+                e("s_add_u32 {n0}, {wbase}, 64")
             e("v_add_u32 {VR}, {n0}, {v_lane}")
             e("buffer_load_ubyte {winb_next}, {VR}, {in_rsrc}, 0 offen")
             if PRIO > 0 and PRIO_TIME:
@@ -1414,6 +1484,15 @@ class Gen:
                 e("s_add_u32 {n1}, {n1}, {prioph}")
                 self.set_prio(R("n1"), R("n0"))
             e("s_setpc_b64 " + RET)
+            if EOFWRAP:
+                lab("Orefill_end")
+                e("s_cmp_eq_u32 {lim}, -1")                   # the byte just taken was already beyond the end: normalize()'s
+                e("s_cbranch_scc1 " + L("Xeof"))              # read error (rangecoder.rs:64)
+                e("s_mov_b32 {lim}, -1")                      # the last byte was taken: from now on the reader is at EOF
+                e("s_mov_b32 {off}, -1")
+                e("s_add_u32 {wbase}, {wbase}, 1")            # (position = wbase + 64 + off stays)
+                self.set_guards(R("n0"))
+                e("s_setpc_b64 " + RET)
 
             lab("Omb_fetch")                                  # lzb.last_n(rep0 + 1)
             e("s_sub_u32 {t1}, {len}, {t0}")
@@ -1443,6 +1522,16 @@ class Gen:
         e("s_cbranch_scc1 " + L("finish2"))
         self.finish_pending()
         lab("finish2")
+        if EOFWRAP:
+            # back to lanes: position = wbase + off, bytes left = lim - off (EOF state: 63 - 63).  Bit 8 of the exit code: the window
+            # pair is not the aligned one the C++ side reads from (last window end-aligned / reader at EOF): it re-seeks before it reads
+            e("s_add_u32 {n0}, {lim}, 1")
+            e("s_cmpk_lt_u32 {n0}, 65")                     # lim in -1 .. 63
+            e("s_cselect_b32 {n0}, 0x100, 0")
+            e("s_or_b32 {exitcode}, {exitcode}, {n0}")
+        if OFFBIAS:
+            e("s_add_u32 {off}, {off}, 64")
+            e("s_add_u32 {lim}, {lim}, 64")
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
@@ -1469,6 +1558,7 @@ def main():
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
     out.append("#define MILZMA_LOOP_PEND_UNKNOWN 0x%xu" % PEND_UNKNOWN)
+    out.append("#define MILZMA_LOOP_EXIT_RESEEK 0x100u   /* or-ed into the exit code: reload the input windows before reading on */")
     for name, lines in texts.items():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
         for l in lines:
