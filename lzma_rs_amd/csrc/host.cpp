@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cinttypes>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +46,12 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+struct UploadTurn {  // whose upload may use the PCIe link now: groups of one call go up in order
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t next = 0;
+};
+
 struct milzma_ctx {
   int device = 0;
   std::string err;
@@ -71,7 +79,14 @@ struct milzma_ctx {
   std::thread batch_thread;
   bool batch_pending = false;
   int batch_rc = 0;
-  milzma_ctx* peer = nullptr;  // a second context on the same device: large whole-file calls alternate their groups between the two
+  // Lanes: further contexts on the same device.  A whole-file call with enough files is cut into groups that run one per lane,
+  // concurrently (grouped_batch).  While a context works as a lane: its uploads wait for their turn (group order, so that the
+  // first group's kernel starts after 1/G of the upload, not after all of it) and its planning budget is its share of the device.
+  std::vector<milzma_ctx*> lanes;
+  struct UploadTurn* turn = nullptr;
+  uint32_t turn_no = 0;
+  bool turn_done = true;
+  uint32_t budget_share = 1;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
   int order_mode = 0;    // MILZMA_ORDER: 0 sorted by input length (default), 1 stride, 2 shuffle (tuning)
@@ -98,6 +113,32 @@ hipStream_t work_stream(milzma_ctx* ctx) {
     ctx->work_stream = nullptr;
   }
   return ctx->work_stream;
+}
+
+// MILZMA_TRACE=1: wall-clock marks of the whole-file batch phases on stderr (tuning)
+void trace_mark(milzma_ctx* ctx, const char* what) {
+  static const bool on = getenv("MILZMA_TRACE") != nullptr;
+  if (!on) return;
+  using namespace std::chrono;
+  static const steady_clock::time_point t0 = steady_clock::now();
+  fprintf(stderr, "[milzma %p group %u] %8.1f ms  %s\n", static_cast<void*>(ctx), ctx->turn ? ctx->turn_no : 0u,
+          duration<double, std::milli>(steady_clock::now() - t0).count(), what);
+}
+
+// (no-ops unless the context is working as a lane of a grouped call)
+void turn_acquire(milzma_ctx* ctx) {
+  if (!ctx->turn || ctx->turn_done) return;
+  std::unique_lock<std::mutex> lock(ctx->turn->mu);
+  ctx->turn->cv.wait(lock, [&] { return ctx->turn->next >= ctx->turn_no; });
+}
+void turn_release(milzma_ctx* ctx) {
+  if (!ctx->turn || ctx->turn_done) return;
+  ctx->turn_done = true;
+  {
+    std::lock_guard<std::mutex> lock(ctx->turn->mu);
+    ctx->turn->next = std::max(ctx->turn->next, ctx->turn_no + 1);
+  }
+  ctx->turn->cv.notify_all();
 }
 
 bool dev_reserve(milzma_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -208,8 +249,16 @@ template <class F>
 bool staged_h2d(milzma_ctx* ctx, void* dev, const void* host, const std::vector<size_t>& bounds, F fill) {
   ChunkedCopy cc;
   if (!cc.stream_ready(ctx)) return false;
+  struct Turn {
+    milzma_ctx* c;
+    ~Turn() { turn_release(c); }
+  } turn{ctx};
+  trace_mark(ctx, "upload: start");
+  if (bounds.size() > 1) fill(0);  // (the first gather does not need the link)
+  turn_acquire(ctx);
+  trace_mark(ctx, "upload: has the turn");
   for (size_t g = 0; g + 1 < bounds.size(); g++) {
-    fill(g);
+    if (g) fill(g);
     const size_t lo = bounds[g], hi = bounds[g + 1];
     if (hi > lo && !hip_ok(ctx,
                            hipMemcpyAsync(static_cast<uint8_t*>(dev) + lo, static_cast<const uint8_t*>(host) + lo, hi - lo,
@@ -217,7 +266,9 @@ bool staged_h2d(milzma_ctx* ctx, void* dev, const void* host, const std::vector<
                            "H2D input"))
       return false;
   }
-  return hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize");
+  const bool ok = hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize");
+  trace_mark(ctx, "upload: done");
+  return ok;
 }
 
 }  // namespace
@@ -261,8 +312,8 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
 extern "C" void milzma_destroy(milzma_ctx* ctx) {
   if (!ctx) return;
   if (ctx->batch_thread.joinable()) ctx->batch_thread.join();
-  if (ctx->peer) milzma_destroy(ctx->peer);
-  ctx->peer = nullptr;
+  for (milzma_ctx* lane : ctx->lanes) milzma_destroy(lane);
+  ctx->lanes.clear();
   (void)hipSetDevice(ctx->device);
   dev_release(ctx->units);
   dev_release(ctx->order);
@@ -555,9 +606,9 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   for (int c = 0; c < kNumLitClasses; c++)
     if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream)) return fail();
 
-  if (!hip_ok(ctx, hipMemcpyAsync(ctx->pin_results.p, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
-              "D2H results"))
-    return fail();
+  // (The results are fetched by the wait half, after the kernels: a copy queued behind a running kernel parks a DMA queue on
+  //  that kernel's completion, and an unrelated upload of another context that lands on the same queue then waits for the whole
+  //  kernel -- measured: 200 ms per grouped call, profiles/r03_batch_api.txt.)
   return MILZMA_OK;
 }
 
@@ -577,7 +628,10 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
   if (n == 0) return MILZMA_OK;
   hipStream_t stream = ctx->pend_stream;
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") ||
-      !collect_kernel_ms(ctx))
+      !collect_kernel_ms(ctx) ||
+      !hip_ok(ctx, hipMemcpyAsync(ctx->pin_results.p, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
+              "D2H results") ||
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
     return MILZMA_INFRA_ERROR;
   memcpy(results, ctx->pin_results.p, size_t(n) * sizeof(milzma_result));
 
@@ -1209,7 +1263,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     ChunkedCopy d2h;  // the output comes back in chunks; a stream is handed over as soon as its slice has arrived
     if (!pin_reserve(ctx, ctx->pin_out, out_bytes) || !dev_reserve(ctx, ctx->out, out_bytes + 512) ||
         milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), work_stream(ctx)) != MILZMA_OK ||
-        !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes)) {
+        (trace_mark(ctx, "decode: done"), !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes))) {
       for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
       finish_alone();
       return MILZMA_INFRA_ERROR;
@@ -1228,6 +1282,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       }
       finish_stream(r[j], kind, hout + sub[j].out_off, size_t(sub[j].out_cap), hdr[i], &outs[i]);
     });
+    trace_mark(ctx, "download + hand-over: done");
     std::vector<uint32_t> next;
     for (size_t j = 0; j < sub.size(); j++)
       if (again[j]) {
@@ -1602,7 +1657,7 @@ size_t plan_budget(milzma_ctx* ctx) {
   if (const char* e = getenv("MILZMA_PLAN_BUDGET")) return size_t(strtoull(e, nullptr, 0));
   size_t free_b = 0, total_b = 0;
   if (!ctx || hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return size_t(1) << 32;
-  return free_b / 4 * 3 + ctx->in.cap + ctx->out.cap;
+  return (free_b / 4 * 3) / std::max(1u, ctx->budget_share) + ctx->in.cap + ctx->out.cap;
 }
 
 // Best-effort parse of footer + Index.  Any oddity => false (the exact walk then decodes on
@@ -1831,27 +1886,45 @@ extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_
   }
 }
 
-// A call with at least two chip-fulls of work is cut into groups of >= kGroupUnits decode units (whole files) that alternate between
-// the context and a peer context on the same device, each group on its own host thread: the upload of group k + 1 and the download +
-// hand-over of group k - 1 run under group k's kernel (one group alone cannot overlap its own three phases: every stream takes the
-// whole kernel).  units_of(i): decode units file i contributes (1 per stream, blocks per .xz file).
+// Large whole-file calls are cut into groups of whole files that run on "lanes" (the context itself + further contexts on the same
+// device), each group on its own host thread, its copies and kernel on the lane's own streams; uploads take turns in group order.
+//  * default, 2 lanes, groups of >= 4096 decode units (a chip-full each): calls with >= 8192 units; the upload of group k + 1 and the
+//    download + hand-over of group k - 1 run under group k's kernel.  One group alone cannot overlap its own three phases (every
+//    stream takes the whole kernel), and this form does not need two kernels to run at once.
+//  * MILZMA_LANES=3|4: groups of 512..2048 units, one per lane, kernels of different lanes running CONCURRENTLY (a stream's wave
+//    is bound by its own instruction chain -- 104 cycles per decision with 4 waves on its SIMD, 80 alone: DESIGN.md 4.1 -- so a
+//    group's kernel takes no longer next to the others than the single launch would, and starts after ITS share of the upload).
+//    Measured (profiles/r03_batch_api.txt): 4096 files in one call 13.0 instead of 12.05 GB/s, 8192 files 14.7 instead of 13.6 --
+//    but only if every lane's two streams get hardware queues of their own: the HIP runtime's default is 4 queues per device
+//    (GPU_MAX_HW_QUEUES), streams beyond that share one and their kernels AND copies serialise (same call: 9.5 GB/s).  Hence opt-in,
+//    for deployments that export GPU_MAX_HW_QUEUES >= 2 x lanes + 1.
+// units_of(i): decode units file i contributes (1 per stream, blocks per .xz file).
 namespace {
 
-constexpr uint32_t kGroupUnits = 4096;
+constexpr uint32_t kChipUnits = 4096, kMinGroupUnits = 512, kMaxGroupUnits = 2048, kMaxLanes = 4;
+
+uint32_t lanes_wanted() {
+  const char* e = getenv("MILZMA_LANES");
+  return e ? std::min<uint32_t>(kMaxLanes, std::max(1, atoi(e))) : 2u;
+}
 
 template <class Units, class Call>
 int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, milzma_output* outs, Units units_of,
                   Call call) {
   std::vector<uint32_t> cut{0};
+  const uint32_t want = lanes_wanted();
   if (ctx && n && ins && in_lens && !getenv("MILZMA_NO_GROUPS")) {
     uint64_t total = 0, acc = 0;
     std::vector<uint32_t> u(n);
     for (uint32_t i = 0; i < n; i++) total += (u[i] = units_of(i));
-    if (total >= 2 * uint64_t(kGroupUnits)) {
-      const uint64_t groups = total / kGroupUnits, per = (total + groups - 1) / groups;  // equal groups, each a full chip or more
+    const bool small = want > 2;
+    const uint64_t least = small ? kMinGroupUnits : kChipUnits;
+    if (want > 1 && total >= 2 * least) {
+      const uint64_t per = small ? std::min<uint64_t>(kMaxGroupUnits, std::max<uint64_t>(kMinGroupUnits, (total + want - 1) / want))
+                                 : (total + total / kChipUnits - 1) / (total / kChipUnits);  // equal groups, each a chip-full or more
       for (uint32_t i = 0; i < n; i++) {
         acc += u[i];
-        if (acc >= per && i + 1 < n && total - acc >= kGroupUnits / 2) {
+        if (acc >= per && i + 1 < n && total - acc >= least / 2) {
           cut.push_back(i + 1);
           total -= acc;
           acc = 0;
@@ -1860,26 +1933,46 @@ int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const 
     }
   }
   cut.push_back(n);
-  if (cut.size() <= 2) return call(ctx, n, ins, in_lens, outs);
-  if (!ctx->peer && milzma_create(ctx->device, &ctx->peer) != MILZMA_OK) return call(ctx, n, ins, in_lens, outs);
-  milzma_ctx* lane[2] = {ctx, ctx->peer};
-  std::thread th[2];
-  int rc[2] = {MILZMA_OK, MILZMA_OK}, worst = MILZMA_OK;
-  for (size_t g = 0; g + 1 < cut.size(); g++) {
-    const int k = int(g & 1);
-    if (th[k].joinable()) {
-      th[k].join();
-      if (rc[k] != MILZMA_OK) worst = rc[k];
-    }
-    const uint32_t lo = cut[g], m = cut[g + 1] - cut[g];
-    th[k] = std::thread([&, k, lo, m] { rc[k] = call(lane[k], m, ins + lo, in_lens + lo, outs + lo); });
+  const size_t groups = cut.size() - 1;
+  if (groups <= 1) return call(ctx, n, ins, in_lens, outs);
+  const size_t nl = std::min<size_t>(want, groups);
+  while (ctx->lanes.size() + 1 < nl) {
+    milzma_ctx* lane = nullptr;
+    if (milzma_create(ctx->device, &lane) != MILZMA_OK) return call(ctx, n, ins, in_lens, outs);
+    ctx->lanes.push_back(lane);
   }
-  for (int k = 0; k < 2; k++)
-    if (th[k].joinable()) {
-      th[k].join();
-      if (rc[k] != MILZMA_OK) worst = rc[k];
+  UploadTurn turn;
+  std::vector<std::thread> th;
+  std::vector<int> rc(nl, MILZMA_OK);
+  for (size_t k = 0; k < nl; k++)
+    th.emplace_back([&, k] {
+      milzma_ctx* lane = k ? ctx->lanes[k - 1] : ctx;
+      lane->turn = &turn;
+      lane->budget_share = uint32_t(nl);
+      for (size_t g = k; g < groups; g += nl) {
+        lane->turn_no = uint32_t(g);
+        lane->turn_done = false;
+        const uint32_t lo = cut[g], m = cut[g + 1] - cut[g];
+        int r = MILZMA_INFRA_ERROR;
+        try {
+          r = call(lane, m, ins + lo, in_lens + lo, outs + lo);
+        } catch (const std::exception& e) {
+          lane->err = std::string("host exception: ") + e.what();
+          for (uint32_t i = lo; i < lo + m; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
+        }
+        turn_release(lane);  // (a group that never reached its upload must not hold up the ones behind it)
+        if (r != MILZMA_OK) rc[k] = r;
+      }
+      lane->turn = nullptr;
+      lane->budget_share = 1;
+    });
+  for (auto& t : th) t.join();
+  int worst = MILZMA_OK;
+  for (size_t k = 0; k < nl; k++)
+    if (rc[k] != MILZMA_OK) {
+      worst = rc[k];
+      if (k && ctx->err.empty()) ctx->err = ctx->lanes[k - 1]->err;
     }
-  if (worst != MILZMA_OK && ctx->peer && !ctx->peer->err.empty() && ctx->err.empty()) ctx->err = ctx->peer->err;
   return worst;
 }
 

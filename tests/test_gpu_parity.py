@@ -795,19 +795,29 @@ def test_whole_file_batches_async_two_in_flight(ctx):
         other.close()
 
 
-def test_large_batch_calls_are_grouped_over_two_contexts(ctx):
+def test_large_batch_calls_are_grouped_over_lanes(ctx, monkeypatch):
     """>= 8192 decode units in one whole-file call: the library cuts it into chip-sized groups that alternate between the context and
-    a peer context (uploads / downloads of one group under the other's kernel).  Same results as small calls, every file in place."""
+    a second context of the same device (uploads in group order; the download of one group under the other's kernel).  With
+    MILZMA_LANES=4: groups of 512..2048 units on four contexts at once (8300 files = 5 groups, 1100 files = 2).  Same results as
+    small calls, every file in place."""
     plains = [W.make_plain("text" if i % 3 else "random", 200 + (i * 37) % 900, seed=i) for i in range(64)]
     comps = [W.compress_alone(p, dict_size=1 << 12, known_size=(i % 2 == 0)) for i, p in enumerate(plains)]
     comps[7] = comps[7][:30]                                     # a truncated one in every 64
     files = [comps[i % 64] for i in range(8300)]
-    decs = ctx.lzma_batch(files)
     ref = [orc.lzma_decompress(c) for c in comps]
-    for i, d in enumerate(decs):
-        r = ref[i % 64]
-        assert (d.kind, d.msg, d.data) == (r.kind, r.msg, r.out), i
+
+    def check(decs):
+        for i, d in enumerate(decs):
+            r = ref[i % 64]
+            assert (d.kind, d.msg, d.data) == (r.kind, r.msg, r.out), i
+
+    check(ctx.lzma_batch(files))
     xz = [lzma.compress(p * 3, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32) for p in plains[:32]]
     many = [xz[i % 32] for i in range(8200)]
     for i, d in enumerate(ctx.xz_batch(many)):
+        assert d.ok and d.data == plains[i % 32] * 3, i
+    monkeypatch.setenv("MILZMA_LANES", "4")
+    check(ctx.lzma_batch(files))
+    check(ctx.lzma_batch(files[:1100]))
+    for i, d in enumerate(ctx.xz_batch(many[:1500])):
         assert d.ok and d.data == plains[i % 32] * 3, i

@@ -22,7 +22,12 @@ def main():
     config, src, out = sys.argv[1:4]
     key = "decode_fast_asm_kernel"
     counters, dur, passes = {}, [], {}
-    for path in sorted(glob.glob(os.path.join(src, "pass_*", "**", "*counter_collection.csv"), recursive=True)):
+    newest = {}          # one CSV per pass directory: the most recent (a repeated pass leaves the older attempt's file behind)
+    for path in glob.glob(os.path.join(src, "pass_*", "**", "*counter_collection.csv"), recursive=True):
+        name = path[len(src):].strip("/").split("/")[0]
+        if name not in newest or os.path.getmtime(path) > os.path.getmtime(newest[name]):
+            newest[name] = path
+    for path in sorted(newest.values()):
         per = defaultdict(lambda: defaultdict(float))
         for r in csv.DictReader(open(path)):
             if key not in r["Kernel_Name"]:
