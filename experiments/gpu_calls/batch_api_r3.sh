@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, call 20: whole-file batch figures of the final library (results download behind the kernels; default grouping)
+# whole-file batch figures of the final library (results download behind the kernels; default grouping)
 cd $GRAFT_REPO_ROOT
-G=gpurun_out/r3_20; mkdir -p $G
+G=gpurun_out/r3_batch; mkdir -p $G
 timeout 300 python experiments/batch_api_bench.py 4096 32 lzma 6 > $G/lzma.txt 2>/dev/null; echo "rc=$?"; grep -v "generated\|run [01]" $G/lzma.txt
 timeout 300 python experiments/batch_api_bench.py 1024 32 xz 6 > $G/xz.txt 2>/dev/null; echo "rc=$?"; grep -v "generated\|run [01]" $G/xz.txt
 python bench.py --pcie --other-configs none --no-cpu-baseline > $G/bench_pcie.json 2> $G/bench_pcie.err; echo "pcie rc=$?"; python -c "

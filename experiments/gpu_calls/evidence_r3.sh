@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 3, call 14: evidence for the FINAL kernel source (biased window offset + end-aligned last window): PMC passes (each under
+# evidence for the FINAL kernel source (biased window offset + end-aligned last window): PMC passes (each under
 # its own timeout, up to 2 attempts: rocprofv3 --pmc hangs now and then on this pool), kernel-trace stats, then the bench lines.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r3_pmc
-rm -rf $O; mkdir -p $O gpurun_out/r3_14
+rm -rf $O; mkdir -p $O gpurun_out/r3_evidence
 pass() {  # cfg index counters...
   cfg=$1; i=$2; shift 2
   for attempt in 1 2; do
@@ -27,7 +27,7 @@ echo "trace rc=$?"
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/r03_kernel_trace_stats.csv \;
 head -3 $O/r03_kernel_trace_stats.csv
 rm -rf $O/*/pass_*/*/*.db $O/trace/*/*.db 2>/dev/null
-G=gpurun_out/r3_14
+G=gpurun_out/r3_evidence
 ( time python bench.py ) > $G/bench_default.json 2> $G/bench_default.err; echo "default rc=$?"
 python bench.py --distinct 0 --other-configs none --no-cpu-baseline > $G/bench_distinct0.json 2> $G/bench_distinct0.err; echo "distinct0 rc=$?"
 python bench.py --pcie --other-configs none --no-cpu-baseline > $G/bench_pcie.json 2> $G/bench_pcie.err; echo "pcie rc=$?"
@@ -36,7 +36,7 @@ python - <<PY
 import json
 for n in ("default","distinct0","pcie","inproc"):
     try:
-        l=json.loads(open("gpurun_out/r3_14/bench_%s.json"%n).read().strip().splitlines()[-1])
+        l=json.loads(open("gpurun_out/r3_evidence/bench_%s.json"%n).read().strip().splitlines()[-1])
         print(n, l["value"], l["ms_per_step"], l["roofline"].get("kernel_ms"), l["roofline"].get("traffic"), (l.get("roofline_issue") or {}).get("frac"), l.get("pcie_inclusive"), {k:(v["value"], v["roofline"].get("traffic"), (v.get("roofline_issue") or {}).get("frac")) for k,v in l.get("other_configs",{}).items()})
     except Exception as e:
         print(n, "failed", e)

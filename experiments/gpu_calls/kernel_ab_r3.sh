@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 3, call 13: end-aligned last window (EOFWRAP: no off == lim test in the normalisation stubs), GPU suite on it
-O=gpurun_out/r3_13
+# end-aligned last window (EOFWRAP: no off == lim test in the normalisation stubs), GPU suite on it
+O=gpurun_out/r3_ab
 mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/gputests.txt 2>&1
 tail -4 $O/gputests.txt

@@ -61,7 +61,7 @@ def main():
         json.dump({"kernel_source_sha256": bench.kernel_source_hash(), "config": config,
                    "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py --config %s "
                               "--steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none "
-                              "(experiments/gpu_calls/gpu_pmc_r3.sh)" % config,
+                              "(experiments/gpu_calls/evidence_r3.sh)" % config,
                    "dispatches_per_pass": passes, "kernel_ms_under_pmc": round(sum(dur) / max(1, len(dur)), 2),
                    "counters_per_launch": counters, "derived": derived}, f, indent=1)
         f.write("\n")
