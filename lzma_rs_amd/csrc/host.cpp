@@ -355,7 +355,8 @@ struct OutHdr {
   uint64_t magic;
   uint64_t cap;
 };
-constexpr uint64_t kOutMagic = 0x6D696C7A6D61504Full;  // "milzmaPO"
+constexpr uint64_t kOutMagic = 0x6D696C7A6D61504Full;    // "milzmaPO": handed out
+constexpr uint64_t kOutPooled = 0x6D696C7A6D61506Full;   // resting in the pool (a second milzma_free of the same pointer is ignored)
 
 struct OutPool {
   std::mutex mu;
@@ -366,7 +367,10 @@ struct OutPool {
   }
   ~OutPool() {
     for (auto& kv : free_by_cap)
-      for (OutHdr* h : kv.second) free(h);
+      for (OutHdr* h : kv.second) {
+        h->magic = 0;
+        free(h);
+      }
   }
 };
 OutPool& out_pool() {
@@ -394,6 +398,7 @@ uint8_t* out_alloc(size_t n) {
       OutHdr* h = it->second.back();
       it->second.pop_back();
       p.held -= cap;
+      h->magic = kOutMagic;
       return reinterpret_cast<uint8_t*>(h + 1);
     }
   }
@@ -417,6 +422,7 @@ extern "C" void milzma_free(void* ptr) {
       try {
         p.free_by_cap[size_t(h->cap)].push_back(h);
         p.held += size_t(h->cap);
+        h->magic = kOutPooled;
         return;
       } catch (const std::bad_alloc&) {
       }
