@@ -5,7 +5,7 @@
   lzma:           configs[1] through milzma_lzma_decompress_batch, N .lzma files of 1 MiB
 After the two single-call runs: `calls` calls of the same batch with TWO in flight (two contexts, milzma_*_batch_async /
 milzma_batch_wait): the copies and the hand-over of one call overlap the decode kernel of the other.
-Usage: python experiments/batch_api_bench.py [files=1024] [distinct=32] [xz|lzma] [calls=2]"""
+Usage: python experiments/batch_api_bench.py [files=1024] [distinct=32] [xz|lzma] [calls=2] [lzma file size=1048576]"""
 import ctypes
 import os
 import sys
@@ -22,11 +22,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 mode = sys.argv[3] if len(sys.argv) > 3 else "xz"
 calls = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+fsize = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
 
 
 def one(i):
     if mode == "lzma":
-        plain = W.make_plain("text", 1 << 20, seed=100 + i)
+        plain = W.make_plain("text", fsize, seed=100 + i)
         return W.compress_alone(plain, dict_size=65536, known_size=True), plain
     half = (4 * 1048576 - 200_000) // 2
     plain = W.make_plain("text", half, seed=100 + i) + W.make_plain("random", 200_000, seed=200 + i) + \
