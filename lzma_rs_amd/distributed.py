@@ -78,35 +78,38 @@ def scatter_inputs(chunks, device):
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     if world == 1:
         return chunks[0].to(device)
-    lens = torch.zeros(world, dtype=torch.int64, device=device)
+    # gloo moves host tensors only (dry runs: several ranks on a box with fewer GPUs): stage through the host there
+    wire = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    lens = torch.zeros(world, dtype=torch.int64, device=wire)
     if rank == 0:
-        lens = torch.tensor([c.numel() for c in chunks], dtype=torch.int64, device=device)
+        lens = torch.tensor([c.numel() for c in chunks], dtype=torch.int64, device=wire)
     dist.broadcast(lens, src=0)
-    mine = torch.empty(int(lens[rank].item()), dtype=torch.uint8, device=device)
+    mine = torch.empty(int(lens[rank].item()), dtype=torch.uint8, device=wire)
     if rank == 0:
-        reqs = [dist.isend(chunks[r].to(device), dst=r) for r in range(1, world)]
-        mine.copy_(chunks[0].to(device))
+        reqs = [dist.isend(chunks[r].to(wire), dst=r) for r in range(1, world)]
+        mine.copy_(chunks[0].to(wire))
         for q in reqs:
             q.wait()
     else:
         dist.recv(mine, src=0)
-    return mine
+    return mine.to(device)
 
 
 def gather_outputs(local_out, device):
-    """All ranks contribute a uint8 tensor (lengths may differ); rank 0 receives the list."""
+    """All ranks contribute a uint8 tensor (lengths may differ); rank 0 receives the list (on `device`)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     if world == 1:
         return [local_out]
-    n = torch.tensor([local_out.numel()], dtype=torch.int64, device=device)
-    lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    wire = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    n = torch.tensor([local_out.numel()], dtype=torch.int64, device=wire)
+    lens = [torch.zeros(1, dtype=torch.int64, device=wire) for _ in range(world)]
     dist.all_gather(lens, n)
     if rank == 0:
         outs = [local_out]
         for r in range(1, world):
-            buf = torch.empty(int(lens[r].item()), dtype=torch.uint8, device=device)
+            buf = torch.empty(int(lens[r].item()), dtype=torch.uint8, device=wire)
             dist.recv(buf, src=r)
-            outs.append(buf)
+            outs.append(buf.to(device))
         return outs
-    dist.send(local_out, dst=0)
+    dist.send(local_out.to(wire), dst=0)
     return None
