@@ -2269,16 +2269,22 @@ extern "C" int milzma_multi_create(uint64_t device_mask, milzma_multi** out) {
       return MILZMA_INFRA_ERROR;
     }
     if (device_mask == 0) device_mask = count >= 64 ? ~uint64_t(0) : ((uint64_t(1) << count) - 1);
+    // MILZMA_MULTI_REPLICAS=k (testing aid): k contexts per selected device, each treated as a device of its own -- the partition,
+    // the per-device workers and the merge of their results run with several shares on a node that has one GPU.
+    int replicas = 1;
+    if (const char* e = getenv("MILZMA_MULTI_REPLICAS")) replicas = std::min(8, std::max(1, atoi(e)));
     auto* m = new milzma_multi();
     for (int d = 0; d < 64; d++) {
       if (!((device_mask >> d) & 1)) continue;
-      milzma_ctx* c = nullptr;
-      if (d >= count || milzma_create(d, &c) != MILZMA_OK) {
-        g_multi_create_error = "device " + std::to_string(d) + ": " + (d >= count ? std::string("not present") : g_create_error);
-        milzma_multi_destroy(m);
-        return MILZMA_INFRA_ERROR;
+      for (int k = 0; k < replicas; k++) {
+        milzma_ctx* c = nullptr;
+        if (d >= count || milzma_create(d, &c) != MILZMA_OK) {
+          g_multi_create_error = "device " + std::to_string(d) + ": " + (d >= count ? std::string("not present") : g_create_error);
+          milzma_multi_destroy(m);
+          return MILZMA_INFRA_ERROR;
+        }
+        m->ctx.push_back(c);
       }
-      m->ctx.push_back(c);
     }
     *out = m;
     return MILZMA_OK;

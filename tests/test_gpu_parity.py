@@ -696,11 +696,16 @@ def test_differential_fuzz_round(ctx):
 
 # ---- several GPUs behind one handle (milzma_multi_*): with the devices present (one here) the results must be those of the
 #      single-device entry points, whatever the partition ----------------------------------------------------------------
-def test_multi_device_entry_points_match_single_device(ctx):
+@pytest.mark.parametrize("shares", [1, 3])
+def test_multi_device_entry_points_match_single_device(ctx, monkeypatch, shares):
+    """shares = 3: MILZMA_MULTI_REPLICAS makes the handle hold three contexts on device 0, each treated as a device of its own, so
+    that the partition, the per-device workers and the merge of their results run with several shares on a one-GPU box."""
     import ctypes
+    if shares > 1:
+        monkeypatch.setenv("MILZMA_MULTI_REPLICAS", str(shares))
     m = M.MultiContext(1)          # mask 1 = device 0
     try:
-        assert m.devices == [0]
+        assert m.devices == [0] * shares
         rng = random.Random(12)
         plains = [W.make_plain(rng.choice(["text", "random", "repeat"]), rng.randint(1, 90000), seed=i) for i in range(24)]
         comps = [W.compress_alone(p, dict_size=1 << 16, known_size=(i % 2 == 0)) for i, p in enumerate(plains)]
@@ -735,20 +740,20 @@ def test_multi_device_entry_points_match_single_device(ctx):
         import torch
         d_in = torch.frombuffer(bytearray(blob) + bytearray(512), dtype=torch.uint8).cuda()
         d_out = torch.zeros(out_off + 512, dtype=torch.uint8, device="cuda")
-        r3 = m.decode_units(arr, [0] * len(units), [d_in.data_ptr()], [d_out.data_ptr()])
+        r3 = m.decode_units(arr, [i % shares for i in range(len(units))], [d_in.data_ptr()] * shares, [d_out.data_ptr()] * shares)
         got = d_out.cpu().numpy().tobytes()
         for u, a, b in zip(units, r3, r2):
             assert (a.status, a.out_len, a.in_consumed) == (b.status, b.out_len, b.in_consumed)
             n = min(a.out_len, u.out_cap)
             assert got[u.out_off:u.out_off + n] == bytes(o2[u.out_off:u.out_off + n])
-        assert m.kernel_ms()[0] > 0
+        assert all(ms > 0 for ms in m.kernel_ms())
         # descriptor checks as in the single-device host call
         bad = (M.Unit * 1)(units[0])
         bad[0].in_len = len(blob) + 1
         with pytest.raises(M.InfraError):
             m.decode_units_host(bad, bytes(blob), out_off)
         with pytest.raises(M.InfraError):
-            m.decode_units(arr, [1] * len(units), [d_in.data_ptr()], [d_out.data_ptr()])   # no device index 1 in this handle
+            m.decode_units(arr, [shares] * len(units), [d_in.data_ptr()] * shares, [d_out.data_ptr()] * shares)   # no such device index
     finally:
         m.close()
     with pytest.raises(M.InfraError):
