@@ -122,18 +122,21 @@ def test_emulated_lc4_rows_in_vgprs(loops, lc, lp, pb):
     assert sum(int(c[i]) for i in range(len(c)) if emu.prog.region[i].startswith("LOvrow_load")) > 100
 
 
-def test_emulated_reader_at_every_cut(loops):
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # the LP0, GEN, PB4 and LC4 variants of the loop
+def test_emulated_reader_at_every_cut(loops, lc, lp, pb):
     """the loop's reader (end-aligned last window, "reader at EOF" state) against the oracle for EVERY prefix of short streams: known
     size, unknown size with marker, unknown size without marker (finished only if the reader is at EOF with code == 0), lengths
     around the 64-byte window: status, bytes decoded and reader position"""
+    emu = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
     plain = W.make_plain("text", 700, seed=5) + bytes(range(200))
     for known, marker in ((True, False), (False, True)):
-        comp = W.compress_alone(plain, dict_size=4096, known_size=known)
-        lc, lp, pb, ds, us = _hdr(comp)
+        comp = W.compress_alone(plain, dict_size=4096, known_size=known, lc=lc, lp=lp, pb=pb)
+        assert _hdr(comp)[:3] == (lc, lp, pb)
+        _, _, _, ds, us = _hdr(comp)
         for cut in list(range(14, 150)) + list(range(len(comp) - 80, len(comp) + 1)):
             part = comp[:cut]
             ref = orc.lzma_decompress(part)
-            r = loops[True].decode_raw(part[13:], lc, lp, pb, ds, us, out_cap=len(plain) + 8)
+            r = emu.decode_raw(part[13:], lc, lp, pb, ds, us, out_cap=len(plain) + 8)
             if ref.ok:
                 assert r["status"] == "OK" and r["out"] == ref.out and r["in_consumed"] + 13 == ref.in_consumed, (known, cut, r["status"])
             else:
@@ -142,13 +145,13 @@ def test_emulated_reader_at_every_cut(loops):
                 if "failed to fill" in ref.msg:
                     assert r["status"] in ("INPUT_EOF", "RC_INIT") and r["in_consumed"] == len(part) - 13, (known, cut, r)
     # unknown size, no marker: a stream cut exactly where the encoder's flush ends decodes "successfully" iff code == 0 there
-    raw = W.compress_alone(plain, dict_size=4096, known_size=False)
+    raw = W.compress_alone(plain, dict_size=4096, known_size=False, lc=lc, lp=lp, pb=pb)
     body = raw[:5] + b"\xff" * 8 + raw[13:]
     for cut in range(len(body) - 12, len(body) + 1):
         part = body[:cut]
         ref = orc.lzma_decompress(part)
-        lc, lp, pb, ds, us = _hdr(part)
-        r = loops[True].decode_raw(part[13:], lc, lp, pb, ds, us, out_cap=len(plain) + 300)
+        _, _, _, ds, us = _hdr(part)
+        r = emu.decode_raw(part[13:], lc, lp, pb, ds, us, out_cap=len(plain) + 300)
         assert (r["status"] == "OK") == ref.ok, (cut, r["status"], ref)
         if ref.ok:
             assert r["out"] == ref.out and r["in_consumed"] + 13 == ref.in_consumed
