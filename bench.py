@@ -273,13 +273,21 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash):
 
 
 def pmc_traffic(config, khash):
-    """HBM bytes per launch from the recorded PMC passes of this kernel source (profiles/r03_pmc_<config>.json), else None"""
+    """HBM bytes per launch from the recorded PMC passes (profiles/r03_pmc_<config>.json): of this kernel source, or of an earlier one the
+    record explicitly names this source compatible with (`also_valid_for`: the loop's memory instructions unchanged; the reason is in
+    the record and repeated in the line as `traffic_recorded_on`).  Returns (bytes or None, note or None)."""
     path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % config)
     if not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
         pmc = json.load(f)
-    return pmc.get("derived", {}).get("hbm_bytes_per_launch") if pmc.get("kernel_source_sha256") == khash else None
+    val = pmc.get("derived", {}).get("hbm_bytes_per_launch")
+    if pmc.get("kernel_source_sha256") == khash:
+        return val, None
+    ok = pmc.get("also_valid_for", {})
+    if khash in ok:
+        return val, "PMC passes taken on kernel source %s; valid for %s because: %s" % (pmc.get("kernel_source_sha256"), khash, ok[khash])
+    return None, None
 
 
 def tile_units(M, units_d, blob_len, n, distinct, upi, size):
@@ -380,7 +388,8 @@ def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
             "bit_exact": bad == 0, "verified_units": verified, "distinct_items": distinct, "generation_s": round(gen_s, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg,
-                         "traffic": pmc_traffic(name, kernel_source_hash())},
+                         "traffic": pmc_traffic(name, kernel_source_hash())[0],
+                         "traffic_recorded_on": pmc_traffic(name, kernel_source_hash())[1]},
             "roofline_issue": issue_roofline(name, "text", out_bytes, k_ms, kernel_source_hash())}
 
 
@@ -731,9 +740,10 @@ def main():
     if os.path.exists(pmc_path) and args.kind == "text" and (n, size, dict_size) == (cfg["streams"], cfg["size"], cfg["dict"]):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if pmc.get("kernel_source_sha256") == khash and "hbm_bytes_per_launch" in pmc.get("derived", {}):
-            traffic = pmc["derived"]["hbm_bytes_per_launch"]
-            traffic_note = pmc["derived"]["traffic_note"]
+        t, recorded_on = pmc_traffic(args.config, khash)
+        if t is not None:
+            traffic = t
+            traffic_note = pmc["derived"]["traffic_note"] + ("  [" + recorded_on + "]" if recorded_on else "")
         else:
             traffic_note = "profiles/r03_pmc_%s.json was taken with another kernel source (%s)" % (args.config, pmc.get("kernel_source_sha256"))
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once

@@ -55,7 +55,7 @@ struct UploadTurn {  // whose upload may use the PCIe link now: groups of one ca
 struct milzma_ctx {
   int device = 0;
   std::string err;
-  DevBuf units, order, results, scratch, in, out, crc, flags;  // flags: 64 words, one per launch in flight (last-block flags)
+  DevBuf units, order, results, scratch, in, out, crc, flags, slice_q, slice_ctx;  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
   PinBuf pin_in, pin_out, pin_small;
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -89,6 +89,9 @@ struct milzma_ctx {
   uint32_t budget_share = 1;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
+  int slice_mode = 0;        // MILZMA_SLICE: 0 auto (launches that are not a whole number of chip-fulls), 1 always, -1 never ("0"),
+                             // 2 always and every unit parked at every quantum even if nobody waits (tests)
+  uint32_t slice_quantum = 128u << 10;  // MILZMA_QUANTUM: output bytes per turn of a time-sliced launch
   int order_mode = 0;    // MILZMA_ORDER: 0 sorted by input length (default), 1 stride, 2 shuffle (tuning)
   uint32_t lds_pad = 0;  // MILZMA_LDS_PAD: bytes of unused dynamic LDS per block of the fast kernel (occupancy experiments)
 };
@@ -296,6 +299,8 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   if (const char* k = getenv("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
   }
+  if (const char* k = getenv("MILZMA_SLICE")) ctx->slice_mode = !strcmp(k, "2") ? 2 : !strcmp(k, "1") ? 1 : !strcmp(k, "0") ? -1 : 0;
+  if (const char* k = getenv("MILZMA_QUANTUM")) ctx->slice_quantum = std::max<uint32_t>(1u, uint32_t(strtoul(k, nullptr, 0)));
   if (const char* k = getenv("MILZMA_ORDER")) ctx->order_mode = !strcmp(k, "stride") ? 1 : !strcmp(k, "shuffle") ? 2 : 0;
   if (const char* k = getenv("MILZMA_LDS_PAD")) {
     ctx->lds_pad = uint32_t(strtoul(k, nullptr, 0));
@@ -323,6 +328,8 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   dev_release(ctx->out);
   dev_release(ctx->crc);
   dev_release(ctx->flags);
+  dev_release(ctx->slice_q);
+  dev_release(ctx->slice_ctx);
   pin_release(ctx->pin_in);
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
@@ -486,7 +493,32 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     }
     hipEvent_t e0 = ctx->ev_pool[size_t(ctx->ev_used) * 2], e1 = ctx->ev_pool[size_t(ctx->ev_used) * 2 + 1];
     if (!hip_ok(ctx, hipEventRecord(e0, stream), "hipEventRecord")) return false;
-    const hipError_t le = cls == kFast || cls == kFastLc4
+    // Time-sliced form for launches that would leave slots idle in their last round (kernels.h); the parked states need memory
+    // (20-34 KB per unit): if that cannot be had the ordinary launch does the job.
+    bool sliced = false;
+    uint32_t cap = 0;
+    if (cls == kFast || cls == kFastLc4) {
+      const uint32_t resident = fast_resident_blocks(cls == kFastLc4, ctx->lds_pad);
+      sliced = ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
+      if (sliced) {
+        uint64_t entries = m;
+        const uint64_t least = std::max<uint32_t>(1u, ctx->slice_quantum / 4u * 3u);  // (a turn is 0.75 .. 1.5 quanta)
+        for (uint32_t k = 0; k < m; k++) entries += ctx->pend_units[order[i + k]].out_cap / least + 2;
+        const size_t ctx_bytes = slice_ctx_bytes(cls == kFastLc4) * ctx->pend_n;  // (indexed by unit, not by launch position)
+        const std::string keep = ctx->err;
+        if (entries > 0x7FFFFFF0ull || !dev_reserve(ctx, ctx->slice_q, slice_queue_bytes(uint32_t(entries))) ||
+            !dev_reserve(ctx, ctx->slice_ctx, ctx_bytes)) {
+          sliced = false;
+          ctx->err = keep;
+        }
+        cap = uint32_t(entries);
+      }
+    }
+    const hipError_t le = sliced
+                              ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
+                                                   static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
+                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p)
+                          : cls == kFast || cls == kFastLc4
                               ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                             static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
                               : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,

@@ -30,6 +30,17 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                        milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag);
 
+// Time-sliced form of the same kernel for launches that are not a whole number of chip-fulls: as many persistent waves as the chip
+// holds take the units from a queue (d_queue: slice_queue_bytes(cap) bytes; cap = n + every yield there can be), decode `quantum`
+// bytes of output per turn and -- while other units wait (always_park: in any case, a testing mode) -- park the unit's state in
+// d_ctxmem (slice_ctx_bytes(lc4) per unit) and take the unit that has waited longest.
+uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad);
+size_t slice_ctx_bytes(bool lc4);
+size_t slice_queue_bytes(uint32_t cap);
+hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
+                              milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem);
+
 // Partial CRCs (64 chunks per unit) of the units' decoded output; see crc_units.hip.h.
 struct CrcParts;
 constexpr size_t kCrcPartsBytes = 64 * 4 + 64 * 8 + 8;

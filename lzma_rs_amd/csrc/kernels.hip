@@ -1,6 +1,8 @@
 // kernels.hip -- HIP translation unit: decode kernels for gfx950 and their launchers.
 #include "kernels.h"
 
+#include <algorithm>
+
 #include "decode_generic.hip.h"
 #include "decode_fast_asm.hip.h"
 #include "crc_units.hip.h"
@@ -38,7 +40,7 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 // Blocks of the fast kernel the current device holds at once (occupancy API x CU count, asked once per instantiation;
 // the data-sheet figures -- 256 CUs x 16, or x 9 for the LC4 instantiation -- if the API fails).  Only decides whether the
 // priority rotation starts with the launch: a wrong value costs time, never correctness.
-static uint32_t resident_blocks(bool lc4, uint32_t lds_pad) {
+uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad) {
   static uint32_t cached[2] = {0, 0};
   if (lds_pad == 0 && cached[lc4]) return cached[lc4];
   uint32_t r = lc4 ? 256u * 9u : 256u * 16u;
@@ -61,7 +63,7 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
   // d_flag: a device word per launch that the launch's last block raises: the waves rotate their priorities (finish
   // together) only once no block is waiting for a slot any more; until then staggered finishes refill slots early
   // (5120 streams: 13.5 vs 11.2 GB/s).  A launch that is a whole number of rounds rotates from the start (8192: 17.2 vs 16.2).
-  const uint32_t resident = resident_blocks(lc4, lds_pad);
+  const uint32_t resident = fast_resident_blocks(lc4, lds_pad);
   if (hipError_t e = hipMemsetAsync(d_flag, n % resident == 0 ? 1 : 0, sizeof(uint32_t), stream); e != hipSuccess) return e;
   // lds_pad: unused dynamic LDS (MILZMA_LDS_PAD, tuning only): what an LDS-resident window of that size would do to occupancy
   if (lc4)
@@ -70,6 +72,26 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
   else
     hipLaunchKernelGGL(decode_fast_asm_kernel<8>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results,
                        d_flag);
+  return hipGetLastError();
+}
+
+size_t slice_ctx_bytes(bool lc4) { return size_t(lc4 ? SliceCtx<16>::kDwords : SliceCtx<8>::kDwords) * sizeof(uint32_t); }
+size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap) * sizeof(uint32_t); }
+
+hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
+                              milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem) {
+  if (n == 0) return hipSuccess;
+  auto* q = static_cast<SliceQueue*>(d_queue);
+  auto* ring = reinterpret_cast<uint32_t*>(q + 1);
+  if (hipError_t e = hipMemsetAsync(d_flag, 1, sizeof(uint32_t), stream); e != hipSuccess) return e;  // all waves start together: rotate
+  const uint32_t waves = std::min(n, fast_resident_blocks(lc4, lds_pad));
+  hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
+                     d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem));
+  if (lc4)
+    hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<16>, dim3(waves), dim3(kWave), lds_pad, stream, q);
+  else
+    hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<8>, dim3(waves), dim3(kWave), lds_pad, stream, q);
   return hipGetLastError();
 }
 

@@ -155,3 +155,36 @@ def test_emulated_reader_at_every_cut(loops, lc, lp, pb):
         assert (r["status"] == "OK") == ref.ok, (cut, r["status"], ref)
         if ref.ok:
             assert r["out"] == ref.out and r["in_consumed"] + 13 == ref.in_consumed
+
+
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # LP0, GEN, PB4, LC4
+def test_emulated_loop_yields_at_quanta(loops, lc, lp, pb):
+    """time-sliced launches: the loop leaves at the first symbol top at or beyond qtop (exit QUANTUM) and is re-entered after the
+    kernel's resume (reader re-seeked, tables rebuilt).  Whatever the quantum -- every symbol, odd sizes, larger than the stream --
+    status, bytes and reader position are those of the uninterrupted run, for good, truncated and size-mismatched streams and at
+    the output limit."""
+    emu = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    rng = random.Random(lc * 100 + lp * 10 + pb)
+    cases = []
+    for kind, n in (("text", 6000), ("random", 1500), ("repeat", 9000), ("zeros", 3000)):
+        plain = W.make_plain(kind, n, seed=rng.randrange(1 << 20))
+        for known in (True, False):
+            comp = W.compress_alone(plain, dict_size=4096, known_size=known, lc=lc, lp=lp, pb=pb)
+            cases.append((comp, len(plain) + 8))
+            cases.append((comp[:len(comp) * 2 // 3], len(plain) + 8))                    # truncated
+        comp = W.compress_alone(plain, dict_size=4096, known_size=True, lc=lc, lp=lp, pb=pb)
+        cases.append((comp[:5] + struct.pack("<Q", n - 7) + comp[13:], len(plain) + 8))   # declared size too small
+        cases.append((comp, n - 100))                                                     # output limit inside the stream
+    most = 0
+    for comp, cap in cases:
+        _, _, _, ds, us = _hdr(comp)
+        base = emu.decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=cap)
+        for q in (1, 97, 2500, 1 << 20):
+            r = emu.decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=cap, quantum=q)
+            assert (r["status"], r["out"], r["len"], r["in_consumed"]) == (base["status"], base["out"], base["len"], base["in_consumed"]), q
+            if q == 1 and base["len"] > 50:
+                assert r["yields"] >= 1          # (a stream of a few long matches has few symbol tops)
+                most = max(most, r["yields"])
+            if q == 1 << 20:
+                assert r["yields"] == 0
+    assert most > 1000                           # quantum 1 on random data: a yield at (nearly) every symbol

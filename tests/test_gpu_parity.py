@@ -826,3 +826,56 @@ def test_large_batch_calls_are_grouped_over_lanes(ctx, monkeypatch):
     check(ctx.lzma_batch(files[:1100]))
     for i, d in enumerate(ctx.xz_batch(many[:1500])):
         assert d.ok and d.data == plains[i % 32] * 3, i
+
+
+def test_time_sliced_launches_match_ordinary_ones(monkeypatch):
+    """The persistent, time-sliced form of the fast kernel (launches that are not a whole number of chip-fulls): every unit parked at
+    every quantum and taken up again by whichever wave is free (MILZMA_SLICE=2, a 2 KiB quantum) -- and the automatic form, 4100
+    units on a chip that holds 4096 waves -- give the oracle's results for good, truncated and damaged .lzma streams of all
+    property classes, LZMA2 streams with every chunk kind, and .xz files."""
+    rng = random.Random(77)
+    plains, comps = [], []
+    for i in range(40):
+        kind = rng.choice(["text", "random", "repeat", "zeros"])
+        lc, lp, pb = rng.choice([(3, 0, 2), (0, 2, 0), (1, 1, 4), (4, 0, 2), (2, 2, 3), (0, 0, 0)])
+        p = W.make_plain(kind, rng.randint(1, 60000), seed=1000 + i)
+        c = W.compress_alone(p, dict_size=rng.choice([4096, 1 << 16, 1 << 20]), known_size=(i % 2 == 0), lc=lc, lp=lp, pb=pb)
+        if i % 7 == 3:
+            c = c[:len(c) * 3 // 5]                                  # truncated
+        if i % 7 == 5:
+            k = 13 + len(c) // 2
+            c = c[:k] + bytes([c[k] ^ 0x5A]) + c[k + 1:]            # damaged in the middle
+        plains.append(p)
+        comps.append(c)
+    ref = [orc.lzma_decompress(c) for c in comps]
+    raws = [lzma.compress(W.make_plain("text", 3 << 20, seed=5), format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}]),
+            lzma.compress(os.urandom(300000) + b"abc" * 50000, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 20}])]
+    raws.append(raws[0][:len(raws[0]) // 2])
+    ref2 = [orc.lzma2_decompress(r) for r in raws]
+    xzs = [lzma.compress(p * 3, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64) for p in plains[:6]]
+
+    def check(c):
+        for d, r in zip(c.lzma_batch(comps), ref):
+            assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
+        for d, r in zip(c.lzma2_batch(raws), ref2):
+            assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
+        for d, p in zip(c.xz_batch(xzs), plains):
+            assert d.ok and d.data == p * 3
+
+    monkeypatch.setenv("MILZMA_SLICE", "2")
+    monkeypatch.setenv("MILZMA_QUANTUM", "2048")
+    c = M.Context(0)
+    try:
+        check(c)
+    finally:
+        c.close()
+    monkeypatch.delenv("MILZMA_SLICE")
+    monkeypatch.delenv("MILZMA_QUANTUM")
+    c = M.Context(0)       # automatic: 4100 streams do not fill a whole number of rounds -> sliced, 128 KiB quanta
+    try:
+        many = [comps[i % 40] for i in range(4100)]
+        for i, d in enumerate(c.lzma_batch(many)):
+            r = ref[i % 40]
+            assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed), i
+    finally:
+        c.close()

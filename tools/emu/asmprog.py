@@ -264,8 +264,10 @@ class AsmLoop:
             self.L.emu_set_s(self.h, i + k, w)
 
     # ---- the kernel around the loop (decode_fast_asm.hip.h), raw LZMA units only ------------------------------
-    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0):
-        """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode)."""
+    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None):
+        """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode).
+        quantum: output bytes after which the loop yields at the next symbol top (the time-sliced launches); the front end then does
+        what the kernel's resume does (re-seeks the reader from its position, has the per-lane tables rebuilt) and re-enters."""
         G = self.G
         if out_cap is None:
             out_cap = unpacked_size if unpacked_size is not None else len(payload) * 64 + 4096
@@ -351,13 +353,27 @@ class AsmLoop:
         self.set_rsrc("out_rsrc", OUT0, out_cap)
         executed = 0
         status = None
+        yields = 0
         while True:
+            S("qtop", min(0xFFFFFFFF, self.sget("len") + quantum) if quantum else 0xFFFFFFFF)
             n = self.L.emu_run(self.h, 0, max_steps)
             if n < 0:
                 raise RuntimeError("emulator: " + self.L.emu_error(self.h).decode())
             executed += n
             ex = self.sget("exitcode") & 0xFF      # (bit 8: "re-seek before reading on" -- positions are right either way)
             S("exitcode", ex)
+            if ex == G.EXIT["QUANTUM"]:
+                # resume: seek(vpos(), rem()) -- aligned windows, off = lane -- and tables rebuilt on entry
+                yields += 1
+                v = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF
+                r = (self.sget("lim") - self.sget("off")) & 0xFFFFFFFF
+                S("wbase", v & ~63)
+                S("off", v & 63)
+                S("lim", (v & 63) + r)
+                self.vset(self._vidx("winb"), window(v & ~63))
+                self.vset(self._vidx("winb_next"), window((v & ~63) + 64))
+                S("tbl_ready", 0)
+                continue
             if ex != G.EXIT["LZ_SLOW"]:
                 break
             # append_lz_slow: matches of >= 64 bytes or running into the output limit
@@ -399,7 +415,7 @@ class AsmLoop:
         if status == ST_INPUT_EOF:
             in_consumed = in_len
         return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,
-                    executed=executed)
+                    executed=executed, yields=yields)
 
     # ---- executed-instruction statistics ------------------------------------------------------------------
     def counts(self):

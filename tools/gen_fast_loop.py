@@ -112,6 +112,11 @@ OFFBIAS = os.environ.get("MILZMA_GEN_OFFBIAS", "1") == "1"
 # current window; -1 = nothing left at all (then off = -1: the next byte asked for carries at once and is the EOF error).
 # Invariant everywhere: reader position = wbase + 64 + off (biased).
 EOFWRAP = OFFBIAS and os.environ.get("MILZMA_GEN_EOFWRAP", "1") == "1"
+# PINV = first VGPR of a fixed block for the model registers the compiler otherwise places (OPS_INOUT_V: 35 registers); 0 = its choice.
+# (The same loop ran 33 % slower inside the time-sliced kernel than inside the ordinary one at 4 waves per SIMD, identical text,
+#  different register numbers: with the block pinned both kernels run the loop on the same registers.)
+PINV = int(os.environ.get("MILZMA_GEN_PINV", "0"))
+ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
@@ -161,7 +166,7 @@ set_layout(False)
 CLOBBER_S = sorted(set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ DM, the refill return address)
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
-            MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9)
+            MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9, QUANTUM=10)
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
                "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc", "tbl_ready"]
@@ -171,7 +176,7 @@ OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_p
                # pb 3 / 4 (PB4 variant): position states 4..15
                "m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b",
                "m_rlen_mid_b"]
-OPS_IN_S = ["out_lim", "safe_len", "target", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
+OPS_IN_S = ["out_lim", "safe_len", "target", "qtop", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
             "out_rsrc", "ldsbase", "flagptr"]
 OPS_IN_V = ["v_lane"]
 FIXED_OPERANDS = {"range": "s66", "code": "s67"}   # an aligned pair, for s_cselect_b64
@@ -635,6 +640,7 @@ class Gen:
         e = self.e
         e("s_add_u32 {t}, {safe_len}, 1", t=t)
         e("s_min_u32 {gtop}, {target}, {t}", t=t)
+        e("s_min_u32 {gtop}, {gtop}, {qtop}")             # the scheduler's quantum: yield at the first symbol top with len >= qtop
         # gtop = 0 (every symbol looks closer) while the reader may be at EOF before the symbol ends.  (lim is a u32 of up to 4 GiB:
         # no signed compares on it)
         if EOFWRAP:
@@ -871,6 +877,13 @@ class Gen:
                 lab("match" + tag + "2")
                 e("s_branch " + L("match2"))
             lab("Otop_slow" + tag)
+            # the wave's turn with this unit is over (time-sliced launches; qtop = all ones otherwise): nothing of this symbol has been
+            # looked at, the loop is re-entered at this very top.  (A literal that landed ON the output limit is undone first, below.)
+            e("s_cmp_gt_u32 {len}, {out_lim}")
+            e("s_cbranch_scc1 " + L("Otop_lim" + tag))
+            e("s_cmp_ge_u32 {len}, {qtop}")
+            e("s_cbranch_scc1 " + L("Xquantum"))
+            lab("Otop_lim" + tag)
             # a literal decoded at len == out_lim < target: append_literal's error (lzbuffer.rs:206-217); its store fell
             # outside the slice or beyond out_len.  (len > out_lim >= target: a last match overshot the size, below.)
             e("s_cmp_lt_u32 {out_lim}, {target}")
@@ -1508,7 +1521,7 @@ class Gen:
             for name, code in [("Xdone_size", "DONE_SIZE"), ("Xdone_fin", "DONE_FIN"), ("Xeof", "INPUT_EOF"),
                                ("Xmarker", "MARKER"), ("Xlimit", "LIMIT"), ("Xlz_slow", "LZ_SLOW"),
                                ("Xmatch_dist_dict", "MATCH_DIST_DICT"), ("Xmatch_dist_out", "MATCH_DIST_OUT"),
-                               ("Xlz_dist_dict", "LZ_DIST_DICT"), ("Xlz_dist_out", "LZ_DIST_OUT")]:
+                               ("Xlz_dist_dict", "LZ_DIST_DICT"), ("Xlz_dist_out", "LZ_DIST_OUT"), ("Xquantum", "QUANTUM")]:
                 lab(name)
                 self.exit_with(code)
 
@@ -1561,12 +1574,14 @@ def main():
     out.append("#define MILZMA_LOOP_EXIT_RESEEK 0x100u   /* or-ed into the exit code: reload the input windows before reading on */")
     for name, lines in texts.items():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
+        if ALIGN:
+            out.append('  ".p2align %d\\n\\t" \\' % ALIGN)
         for l in lines:
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
     assert clobbers["LP0"] == clobbers["GEN"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["GEN"] == fixeds["PB4"]
     common = ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
-              ['[%s] "+v"(d.%s)' % (n, n) for n in OPS_INOUT_V])
+              [('[%s] "+{v%d}"(d.%s)' % (n, PINV + i, n)) if PINV else ('[%s] "+v"(d.%s)' % (n, n)) for i, n in enumerate(OPS_INOUT_V)])
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
     for sfx, name in (("", "LP0"), ("_LC4", "LC4")):
         out.append("#define MILZMA_FAST_LOOP_OUTPUTS%s \\" % sfx)
