@@ -85,7 +85,24 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
   auto* q = static_cast<SliceQueue*>(d_queue);
   auto* ring = reinterpret_cast<uint32_t*>(q + 1);
   if (hipError_t e = hipMemsetAsync(d_flag, 1, sizeof(uint32_t), stream); e != hipSuccess) return e;  // all waves start together: rotate
-  const uint32_t waves = std::min(n, fast_resident_blocks(lc4, lds_pad));
+  // persistent waves: what the chip holds of THIS kernel (it keeps more registers alive than the ordinary one; never more than that one's)
+  static uint32_t cached[2] = {0, 0};
+  uint32_t resident = fast_resident_blocks(lc4, lds_pad);
+  if (lds_pad == 0 && cached[lc4]) {
+    resident = cached[lc4];
+  } else {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    const hipError_t e = lc4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<16>, int(kWave), lds_pad)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<8>, int(kWave), lds_pad);
+    if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      resident = std::min(resident, uint32_t(per_cu) * uint32_t(prop.multiProcessorCount));
+    else
+      (void)hipGetLastError();
+    if (lds_pad == 0) cached[lc4] = resident;
+  }
+  const uint32_t waves = std::min(n, resident);
   hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
                      d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem));
   if (lc4)
