@@ -1,0 +1,29 @@
+#!/bin/bash
+# What round 3 ran out of GPU minutes for; meant to be the first call of the next round (about 10 minutes):
+#  1. PMC passes of the CURRENT kernel source for configs[1] and configs[2] (each pass under its own timeout, up to 3 attempts: rocprofv3
+#     --pmc hangs about every other time on this pool), profiles/r03_pmc_*.json rewritten for this hash (they carry an `also_valid_for`
+#     attestation until then);
+#  2. an alternating A/B of the model registers pinned to v20..v54 (MILZMA_GEN_PINV=20; one sample in round 3 said -0.9 %):
+#     build the variant first:  python3 tools/build_variants.py "pinv20:PINV=20"
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/next_pmc; rm -rf $O; mkdir -p $O
+pass() {  # cfg index counters...
+  cfg=$1; i=$2; shift 2
+  for attempt in 1 2 3; do
+    rm -rf $O/$cfg/pass_$i
+    timeout 110 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$cfg/pass_$i -- python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none > $O/${cfg}_pass_$i.log 2>&1
+    n=$(find $O/$cfg/pass_$i -name "*counter_collection.csv" 2>/dev/null | wc -l)
+    echo "$cfg pass $i attempt $attempt rc=$? csv=$n"
+    [ "$n" -gt 0 ] && break
+  done
+}
+for cfg in lzma64k dict8m; do
+  pass $cfg 1 FETCH_SIZE
+  pass $cfg 2 WRITE_SIZE
+  pass $cfg 3 SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY
+  python tools/make_pmc_profile.py $cfg $O/$cfg $O/r03_pmc_$cfg.json > /dev/null 2>&1 && cp $O/r03_pmc_$cfg.json profiles/
+done
+rm -rf $O/*/pass_*/*/*.db 2>/dev/null
+V=lzma_rs_amd/variants/libmilzma_pinv20.so
+[ -f $V ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $V lzma_rs_amd/libmilzma.so $V | tee gpurun_out/next_pinv_ab.txt
