@@ -13,8 +13,9 @@ pass() {  # cfg index counters...
   for attempt in 1 2 3; do
     rm -rf $O/$cfg/pass_$i
     timeout 110 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$cfg/pass_$i -- python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none > $O/${cfg}_pass_$i.log 2>&1
+    rc=$?
     n=$(find $O/$cfg/pass_$i -name "*counter_collection.csv" 2>/dev/null | wc -l)
-    echo "$cfg pass $i attempt $attempt rc=$? csv=$n"
+    echo "$cfg pass $i attempt $attempt rc=$rc csv=$n"
     [ "$n" -gt 0 ] && break
   done
 }
