@@ -501,13 +501,21 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
       const uint32_t resident = fast_resident_blocks(cls == kFastLc4, ctx->lds_pad);
       sliced = ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
       if (sliced) {
-        uint64_t entries = m;
+        uint64_t entries = m, longest = 0;
         const uint64_t least = std::max<uint32_t>(1u, ctx->slice_quantum / 4u * 3u);  // (a turn is 0.75 .. 1.5 quanta)
-        for (uint32_t k = 0; k < m; k++) entries += ctx->pend_units[order[i + k]].out_cap / least + 2;
+        for (uint32_t k = 0; k < m; k++) {
+          const uint64_t cap_k = ctx->pend_units[order[i + k]].out_cap;
+          entries += cap_k / least + 2;
+          longest = std::max(longest, cap_k);
+        }
         const size_t ctx_bytes = slice_ctx_bytes(cls == kFastLc4) * ctx->pend_n;  // (indexed by unit, not by launch position)
+        size_t free_b = 0, total_b = 0;
         const std::string keep = ctx->err;
-        if (entries > 0x7FFFFFF0ull || !dev_reserve(ctx, ctx->slice_q, slice_queue_bytes(uint32_t(entries))) ||
-            !dev_reserve(ctx, ctx->slice_ctx, ctx_bytes)) {
+        // Not worth it / not to be had: units that all end within their first turn are never parked (the hardware's own block dispatch
+        // does as well for them, without a parking lot of 20-34 KB per unit); a parking lot beyond a quarter of the free memory.
+        if ((ctx->slice_mode == 0 && longest <= least) || entries > 0x7FFFFFF0ull ||
+            (ctx_bytes > ctx->slice_ctx.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx_bytes > (free_b + ctx->slice_ctx.cap) / 4) ||
+            !dev_reserve(ctx, ctx->slice_q, slice_queue_bytes(uint32_t(entries))) || !dev_reserve(ctx, ctx->slice_ctx, ctx_bytes)) {
           sliced = false;
           ctx->err = keep;
         }
