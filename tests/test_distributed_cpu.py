@@ -115,3 +115,21 @@ def test_bench_refuses_more_gpus_than_present():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2)], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_traffic_only_from_records_of_this_kernel_source(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic: the recorded PMC figure only if the record was taken on the kernel source being run, or names
+    this source compatible with its own (`also_valid_for`, with the reason -- which the line then repeats); anything else is null."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rec = {"kernel_source_sha256": "aaaa", "derived": {"hbm_bytes_per_launch": 123.0}, "also_valid_for": {"bbbb": "no memory instruction changed"}}
+    (prof / "r03_pmc_lzma64k.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("lzma64k", "aaaa") == (123.0, None)
+    val, note = bench.pmc_traffic("lzma64k", "bbbb")
+    assert val == 123.0 and "aaaa" in note and "no memory instruction changed" in note
+    assert bench.pmc_traffic("lzma64k", "cccc") == (None, None)
+    assert bench.pmc_traffic("dict8m", "aaaa") == (None, None)
