@@ -4,7 +4,9 @@
 #     --pmc hangs about every other time on this pool), profiles/r03_pmc_*.json rewritten for this hash (they carry an `also_valid_for`
 #     attestation until then);
 #  2. an alternating A/B of the model registers pinned to v20..v54 (MILZMA_GEN_PINV=20; one sample in round 3 said -0.9 %):
-#     build the variant first:  python3 tools/build_variants.py "pinv20:PINV=20"
+#  3. the same for the split literal table (MILZMA_GEN_LITSPLIT=1: two scalar shifts less per literal-row swap; bit-exact on the emulator,
+#     -0.14 scalar instructions per byte on text, -1.74 on random data), on text and on random data.
+#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1"
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/next_pmc; rm -rf $O; mkdir -p $O
@@ -28,3 +30,6 @@ done
 rm -rf $O/*/pass_*/*/*.db 2>/dev/null
 V=lzma_rs_amd/variants/libmilzma_pinv20.so
 [ -f $V ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $V lzma_rs_amd/libmilzma.so $V | tee gpurun_out/next_pinv_ab.txt
+W=lzma_rs_amd/variants/libmilzma_litsplit.so
+[ -f $W ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $W lzma_rs_amd/libmilzma.so $W | tee gpurun_out/next_litsplit_ab.txt
+[ -f $W ] && python experiments/ab_bench.py --steps 3 --kind random lzma_rs_amd/libmilzma.so $W | tee -a gpurun_out/next_litsplit_ab.txt
