@@ -6,7 +6,11 @@
 #  2. an alternating A/B of the model registers pinned to v20..v54 (MILZMA_GEN_PINV=20; one sample in round 3 said -0.9 %):
 #  3. the same for the split literal table (MILZMA_GEN_LITSPLIT=1: two scalar shifts less per literal-row swap; bit-exact on the emulator,
 #     -0.14 scalar instructions per byte on text, -1.74 on random data), on text and on random data.
-#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1"
+#  4. FIVE waves per SIMD: the loop generated with all its registers below v96 and the kernel built for 5 waves per SIMD compiles to 96 VGPRs /
+#     occupancy 5 (round 3, CPU only; bit-exact on the emulator).  With 8 KiB of LDS per wave 20 waves are exactly a CU's 160 KiB: does the
+#     hardware hold them?  Then the time-sliced launch runs 5120 persistent waves: the decision chain's micro-benchmark says +11 % for
+#     batches of >= 5120 streams (nothing for 4096).  GPU suite on the variant first, then 4096 / 8192 / 32768 streams against the shipped library.
+#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1" "w5:VBASE=40,PINV=1:+-DMILZMA_WAVES_PER_SIMD=5"
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/next_pmc; rm -rf $O; mkdir -p $O
@@ -33,3 +37,13 @@ V=lzma_rs_amd/variants/libmilzma_pinv20.so
 W=lzma_rs_amd/variants/libmilzma_litsplit.so
 [ -f $W ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $W lzma_rs_amd/libmilzma.so $W | tee gpurun_out/next_litsplit_ab.txt
 [ -f $W ] && python experiments/ab_bench.py --steps 3 --kind random lzma_rs_amd/libmilzma.so $W | tee -a gpurun_out/next_litsplit_ab.txt
+X=$PWD/lzma_rs_amd/variants/libmilzma_w5.so
+if [ -f $X ]; then
+  MILZMA_LIB=$X timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+  for n in 4096 8192 32768; do
+    for lib in lzma_rs_amd/libmilzma.so $X; do
+      MILZMA_LIB=$PWD/${lib#$PWD/} timeout 300 python bench.py --streams $n --steps 2 --warmup 1 --no-cpu-baseline --other-configs none 2>/dev/null | python -c "
+import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$n streams', '$lib'.split('/')[-1], l['value'], 'GB/s', l['ms_per_step'], 'ms', l['bit_exact'])"
+    done
+  done | tee gpurun_out/next_w5.txt
+fi

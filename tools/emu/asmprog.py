@@ -299,7 +299,7 @@ class AsmLoop:
             if name.startswith("m_") or name in ("u0", "u1", "u2", "u3"):
                 self.vset(self._vidx(name), 0x400)
         for i in range(self.lit_regs):
-            self.vset(64 + i, 0x04000400)
+            self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
         for i in range(4):
             self.vset(self.ps0 + i, 0x400)
         if getattr(G, "MVBASE", None) and self.lit_regs == 32:      # LC4: matched rows 12..15 in VGPRs

@@ -120,6 +120,11 @@ PINV = int(os.environ.get("MILZMA_GEN_PINV", "0"))
 # of a row is the row itself, not twice it -- two scalar shifts less per row swap (0.14 per byte on text, 1.75 on random data).
 # Prepared in round 3 (bit-exact on the emulator), not timed yet: default off.
 LITSPLIT = os.environ.get("MILZMA_GEN_LITSPLIT", "0") == "1"
+# VBASE: first register of the loop's fixed VGPR block (literal table, pos_slot trees, temporaries and per-lane constants: 56 registers,
+# 72 for lc + lp = 4).  64 (the default) puts the block's top at v119: the kernel cannot have fewer than 120 VGPRs whatever the compiler
+# does.  40, with the model registers pinned below it (PINV=1: v1..v35), keeps everything the loop names below v96 -- what a fifth wave per
+# SIMD needs (kernel built with -DMILZMA_WAVES_PER_SIMD=5; the time-sliced launch then runs 5120 persistent waves).  Prepared in round 3.
+VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
@@ -146,7 +151,7 @@ if PAD_V:
     _V0["vpad"] = 111
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE = {}, "", "", "", [], 16, None
 VROW0 = 12   # LC4: first matched row that lives in VGPRs
-LIT0, LIT1 = "v64", "v65"   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
+LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
 
 
 def set_layout(lc4):
@@ -155,8 +160,9 @@ def set_layout(lc4):
     global V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE, LIT1
     off = 16 if lc4 else 0
     LIT_REGS = 32 if lc4 else 16
-    LIT1 = "v%d" % (64 + LIT_REGS // 2) if LITSPLIT else "v65"
+    LIT1 = "v%d" % (VBASE + LIT_REGS // 2) if LITSPLIT else "v%d" % (VBASE + 1)
     V.clear()
+    off += VBASE - 64
     V.update({k: "v%d" % (n + off) for k, n in _V0.items()})
     MROW = "v[%d:%d]" % (84 + off, 87 + off)
     PS0 = "v%d" % (80 + off)        # pos_slot trees for len_state 0..3
@@ -1570,7 +1576,7 @@ def main():
         g.finish()
         texts[name] = lines
         clobbers[name] = list(CLOBBER_V)
-        fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (64 + i, i) for i in range(LIT_REGS)] +
+        fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (VBASE + i, i) for i in range(LIT_REGS)] +
                         ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)] +
                         (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16)] if lc4 else []))
     out = []
