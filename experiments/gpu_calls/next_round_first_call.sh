@@ -7,10 +7,10 @@
 #  3. the same for the split literal table (MILZMA_GEN_LITSPLIT=1: two scalar shifts less per literal-row swap; bit-exact on the emulator,
 #     -0.14 scalar instructions per byte on text, -1.74 on random data), on text and on random data.
 #  4. FIVE waves per SIMD: the loop generated with all its registers below v96 and the kernel built for 5 waves per SIMD compiles to 96 VGPRs /
-#     occupancy 5 (round 3; bit-exact; 4096 streams as fast as the shipped build).  With 8 KiB of LDS per wave 20 waves are exactly a CU's
-#     160 KiB and the hardware did NOT hold them at the end of round 3 (5120 streams: two rounds) -- rerun after the LDS per wave is below 8 KiB.  Then the time-sliced launch runs 5120 persistent waves: the decision chain's micro-benchmark says +11 % for
+#     occupancy 5, 7 KiB LDS (round 3; bit-exact; 5120 streams in one round: 18.16 GB/s, +2.9 % chip throughput).  Here: the GPU suite on
+#     it and the large-batch figures with the time-sliced launch on 5120 persistent waves.  Then the time-sliced launch runs 5120 persistent waves: the decision chain's micro-benchmark says +11 % for
 #     batches of >= 5120 streams (nothing for 4096).  GPU suite on the variant first, then 4096 / 8192 / 32768 streams against the shipped library.
-#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1" "w5:VBASE=40,PINV=1:+-DMILZMA_WAVES_PER_SIMD=5"
+#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1" "w5:VBASE=40,PINV=1,VROW8=7,NOPB4=1:+-DMILZMA_WAVES_PER_SIMD=5"
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/next_pmc; rm -rf $O; mkdir -p $O

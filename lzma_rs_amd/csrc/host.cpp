@@ -459,7 +459,7 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   // switches to properties that class is not built for.
   if (u.kind != MILZMA_KIND_RAW_LZMA) return ctx->use_fast ? kFast : kLitLds3;
   const uint32_t lclp = uint32_t(u.lc) + u.lp;
-  if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return kFast;
+  if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return (u.pb > 2 && !fast8_takes_pb4()) ? kFastLc4 : kFast;
   if (ctx->use_fast && u.pb <= 4 && lclp == 4) return kFastLc4;
   if (lclp <= 3) return kLitLds3;
   if (lclp <= 4) return kLitLds4;

@@ -35,6 +35,8 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
 // bytes of output per turn and -- while other units wait (always_park: in any case, a testing mode) -- park the unit's state in
 // d_ctxmem (slice_ctx_bytes(lc4) per unit) and take the unit that has waited longest.
 uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad);
+// false in a build whose 8-row loop has no PB4 variant (five waves per SIMD): RAW units with pb 3 / 4 then start in the LC4 class
+bool fast8_takes_pb4();
 size_t slice_ctx_bytes(bool lc4);
 size_t slice_queue_bytes(uint32_t cap);
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,

@@ -75,6 +75,14 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
   return hipGetLastError();
 }
 
+bool fast8_takes_pb4() {
+#ifdef MILZMA_LOOP_NO_PB4
+  return false;
+#else
+  return true;
+#endif
+}
+
 size_t slice_ctx_bytes(bool lc4) { return size_t(lc4 ? SliceCtx<16>::kDwords : SliceCtx<8>::kDwords) * sizeof(uint32_t); }
 size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap) * sizeof(uint32_t); }
 

@@ -302,8 +302,8 @@ class AsmLoop:
             self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
         for i in range(4):
             self.vset(self.ps0 + i, 0x400)
-        if getattr(G, "MVBASE", None) and self.lit_regs == 32:      # LC4: matched rows 12..15 in VGPRs
-            for i in range(16):
+        if self.mvbase:      # matched rows that live in VGPRs: LC4's rows 12..15, row 7 of the 8-row variants built for five waves per SIMD
+            for i in range(16 if self.lit_regs == 32 else 4 * (8 - getattr(G, "VROW8", 8))):
                 self.vset(self.mvbase + i, 0x04000400)
         lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
         self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)

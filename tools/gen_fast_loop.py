@@ -125,6 +125,12 @@ LITSPLIT = os.environ.get("MILZMA_GEN_LITSPLIT", "0") == "1"
 # does.  40, with the model registers pinned below it (PINV=1: v1..v35), keeps everything the loop names below v96 -- what a fifth wave per
 # SIMD needs (kernel built with -DMILZMA_WAVES_PER_SIMD=5; the time-sliced launch then runs 5120 persistent waves).  Prepared in round 3.
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
+# The rest of what a fifth wave per SIMD needs (20 waves x 8 KiB are exactly a CU's LDS, and the hardware did not place them):
+# VROW8 = 7: in the 8-row variants (lc + lp <= 3) the matched sub-tables of literal row 7 live in 4 VGPRs, rows 0..6 in 7 KiB of LDS
+# (the mechanism the LC4 variant uses for its rows 12..15); NOPB4 = 1: no PB4 variant and none of its 8 model registers -- streams with
+# pb 3 / 4 go to the LC4 instantiation, which handles any pb.  88 registers named by the loop, below v96.
+VROW8 = int(os.environ.get("MILZMA_GEN_VROW8", "8"))
+NOPB4 = os.environ.get("MILZMA_GEN_NOPB4", "0") == "1"
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
@@ -170,7 +176,10 @@ def set_layout(lc4):
     CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
     # LC4: the matched-literal sub-tables of rows 12..15 live in 16 VGPRs (fixed operands, s_set_gpr_idx indexed), rows 0..11 in
     # LDS: 12 KiB per wave instead of 16 -> 13 blocks per CU fit, and the 151 VGPRs allow 12 (3 per SIMD); with 16 KiB it was 9
-    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if lc4 else None
+    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if (lc4 or VROW8 < 8) else None
+    if MVBASE and not lc4 and PINV and "OPS_INOUT_V" in globals():   # the 8-row variants' VGPR rows: behind the pinned model registers
+        MVBASE = PINV + len(OPS_INOUT_V) - (len(PB4_ONLY_V) if NOPB4 else 0)
+        assert MVBASE + 4 * (8 - VROW8) <= VBASE
 
 
 set_layout(False)
@@ -187,6 +196,7 @@ OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_p
                # pb 3 / 4 (PB4 variant): position states 4..15
                "m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b",
                "m_rlen_mid_b"]
+PB4_ONLY_V = ["m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b", "m_rlen_mid_b"]
 OPS_IN_S = ["out_lim", "safe_len", "target", "qtop", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
             "out_rsrc", "ldsbase", "flagptr"]
 OPS_IN_V = ["v_lane"]
@@ -209,6 +219,7 @@ class Gen:
     def __init__(self, lp0, pb4=False, lc4=False):
         set_layout(lc4)  # (lc4: lc + lp = 4 -- 16 literal rows; same code, other register numbers and 16 KiB of LDS rows)
         self.lc4 = lc4
+        self.vrow0 = VROW0 if lc4 else (VROW8 if VROW8 < 8 else None)   # first matched row that lives in VGPRs (None: all in LDS)
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
         # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
@@ -956,17 +967,17 @@ class Gen:
     def mrow_load(self):
         """MROW = the matched sub-tables of literal row `row` (4 dwords per lane)"""
         e, L = self.e, self.L
-        if self.lc4:
-            e("s_cmpk_ge_u32 {row}, %d" % VROW0)
+        if self.vrow0 is not None:
+            e("s_cmpk_ge_u32 {row}, %d" % self.vrow0)
             e("s_cbranch_scc1 " + L("Ovrow_load"))
         e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
         e("ds_read_b128 " + MROW + ", {VA}")
         e("s_waitcnt lgkmcnt(0)")
-        if self.lc4:
+        if self.vrow0 is not None:
             self.lab("lm_b")
             with self.in_cold():
                 self.lab("Ovrow_load")
-                e("s_sub_u32 {t0}, {row}, %d" % VROW0)
+                e("s_sub_u32 {t0}, {row}, %d" % self.vrow0)
                 e("s_lshl_b32 {t0}, {t0}, 2")
                 e("s_set_gpr_idx_on {t0}, gpr_idx(SRC0)")
                 for k in range(4):
@@ -975,19 +986,19 @@ class Gen:
                 e("s_branch " + L("lm_b"))
 
     def mrow_store(self):
-        """the row back where it lives (clobbers SCC and t0 in the LC4 variant)"""
+        """the row back where it lives (clobbers SCC and t0 where some rows live in VGPRs)"""
         e, L = self.e, self.L
-        if not self.lc4:
+        if self.vrow0 is None:
             e("ds_write_b128 {VA}, " + MROW)
             return
         k = self.new("VS")
-        e("s_cmpk_ge_u32 {row}, %d" % VROW0)
+        e("s_cmpk_ge_u32 {row}, %d" % self.vrow0)
         e("s_cbranch_scc1 " + L(k))
         e("ds_write_b128 {VA}, " + MROW)
         self.lab(k + "r")
         with Gen._Into(self, self.cold2):
             self.lab(k)
-            e("s_sub_u32 {t0}, {row}, %d" % VROW0)
+            e("s_sub_u32 {t0}, {row}, %d" % self.vrow0)
             e("s_lshl_b32 {t0}, {t0}, 2")
             e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
             for j in range(4):
@@ -1569,6 +1580,8 @@ def main():
     texts, clobbers, fixeds = {}, {}, {}
     for name, lp0, pb4, lc4 in (("LP0", True, False, False), ("GEN", False, False, False), ("PB4", False, True, False),
                                 ("LC4", False, True, True)):
+        if NOPB4 and name == "PB4":
+            continue
         g = Gen(lp0, pb4, lc4)
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
@@ -1578,7 +1591,7 @@ def main():
         clobbers[name] = list(CLOBBER_V)
         fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (VBASE + i, i) for i in range(LIT_REGS)] +
                         ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)] +
-                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16)] if lc4 else []))
+                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16 if lc4 else 4 * (8 - VROW8))] if MVBASE else []))
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
@@ -1588,6 +1601,10 @@ def main():
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
     out.append("#define MILZMA_LOOP_PEND_UNKNOWN 0x%xu" % PEND_UNKNOWN)
+    if VROW8 != 8:
+        out.append("#define MILZMA_LOOP_VROW8 %d   // 8-row variants: first matched-literal row that lives in VGPRs (default 8: none)" % VROW8)
+    if NOPB4:
+        out.append("#define MILZMA_LOOP_NO_PB4 1   // no PB4 variant: pb 3 / 4 belongs to the LC4 instantiation")
     out.append("#define MILZMA_LOOP_EXIT_RESEEK 0x100u   /* or-ed into the exit code: reload the input windows before reading on */")
     for name, lines in texts.items():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
@@ -1596,13 +1613,17 @@ def main():
         for l in lines:
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
-    assert clobbers["LP0"] == clobbers["GEN"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["GEN"] == fixeds["PB4"]
-    common = ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
-              [('[%s] "+{v%d}"(d.%s)' % (n, PINV + i, n)) if PINV else ('[%s] "+v"(d.%s)' % (n, n)) for i, n in enumerate(OPS_INOUT_V)])
+    assert clobbers["LP0"] == clobbers["GEN"] and fixeds["LP0"] == fixeds["GEN"]
+    assert NOPB4 or (clobbers["LP0"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["PB4"])
+
+    def common(vnames):
+        return ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
+                [('[%s] "+{v%d}"(d.%s)' % (n, PINV + i, n)) if PINV else ('[%s] "+v"(d.%s)' % (n, n)) for i, n in enumerate(vnames)])
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
     for sfx, name in (("", "LP0"), ("_LC4", "LC4")):
         out.append("#define MILZMA_FAST_LOOP_OUTPUTS%s \\" % sfx)
-        out.append("  " + ", \\\n  ".join(common + fixeds[name]))
+        vnames = [n for n in OPS_INOUT_V if not (NOPB4 and name == "LP0" and n in PB4_ONLY_V)]   # (the LC4 variant handles pb 3 / 4 in any case)
+        out.append("  " + ", \\\n  ".join(common(vnames) + fixeds[name]))
         out.append("#define MILZMA_FAST_LOOP_CLOBBERS%s \\" % sfx)
         out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + clobbers[name]) + ', "vcc", "scc", "memory"')
     out.append("#define MILZMA_FAST_LOOP_INPUTS \\")
