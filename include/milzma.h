@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MILZMA_ABI_VERSION 2
+#define MILZMA_ABI_VERSION 3
 
 /* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
 enum {
@@ -87,7 +87,10 @@ enum {
   MILZMA_ST_L2_LCLP = 22,           /* :170-175 "LZMA2 invalid properties: lc + lp ({a} + {b}) must be <= 4" */
   MILZMA_ST_L2_STORED_EOF = 23,     /* :219-225 "LZMA2 expected {a} uncompressed bytes: {io}"            */
   /* not reference errors: conditions of this implementation, resolved by the host layer */
-  MILZMA_ST_OUT_FULL = 32,   /* out_cap reached before the stream ended (grow the slice and retry)     */
+  MILZMA_ST_OUT_FULL = 32,   /* out_cap reached before the stream ended.  err_a == MILZMA_PARKED: the unit stopped in front
+                                of the symbol that would not fit and its decoder state is parked in the context -- give it a
+                                larger slice and call milzma_decode_units_ex(MILZMA_DECODE_RESUME); otherwise (err_a == 0):
+                                grow the slice and decode the unit again from its first byte                              */
   MILZMA_ST_NEED_LCLP = 33,  /* unit needs a literal table for lc+lp = {a} larger than its launch class */
   MILZMA_ST_BAD_UNIT = 34,   /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
   MILZMA_ST_NEED_GENERIC = 35 /* props outside the fast kernel's specialisation: rerun in the generic one */
@@ -103,6 +106,8 @@ typedef struct milzma_result {
   uint64_t in_consumed; /* reader position at return, relative to in_off                               */
   uint64_t err_a, err_b;
 } milzma_result;
+
+#define MILZMA_PARKED 1u /* milzma_result.err_a of a unit that stopped for room and can be resumed */
 
 typedef struct milzma_ctx milzma_ctx;
 
@@ -138,6 +143,33 @@ int milzma_decode_units(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, c
 int milzma_decode_units_async(milzma_ctx *ctx, const milzma_unit *units, uint32_t n,
                               const void *d_in, void *d_out, void *hip_stream);
 int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
+
+/* Growable output -- streams whose size is not known up front (every .lzma that liblzma / `xz --format=lzma` writes ends with a
+ * marker and declares no size; the reference streams such output through its ring without a cap, src/decode/lzbuffer.rs:258-270,
+ * src/decode/lzma.rs:441-455).  milzma_decode_units_ex is milzma_decode_units with `flags`:
+ *   MILZMA_DECODE_GROW    a unit that fills its output slice before its stream ends is PARKED instead of failed: it stops at a
+ *                         symbol boundary within 273 bytes of the slice's end (nothing of the next symbol looked at), its decoder
+ *                         state stays in the context, its result is (MILZMA_ST_OUT_FULL, err_a = MILZMA_PARKED, out_len = bytes
+ *                         produced so far, in_consumed = reader position).  A unit whose declared size fits its slice, or whose
+ *                         limit is a memlimit, is never parked.  Units the generic kernel decodes (lc + lp > 4) are not parked
+ *                         either: they report a plain OUT_FULL (err_a = 0) and must be decoded again from the start.
+ *   MILZMA_DECODE_RESUME  (implies GROW) continues the units the previous _ex call on this context parked: same n, same order;
+ *                         `results` holds that call's results on entry, and only entries that say PARKED are touched.  For every
+ *                         parked unit the descriptor names the NEW output slice (out_off / out_cap; at least 274 bytes more than
+ *                         out_len) whose first out_len bytes hold the output so far -- the unit's dictionary; move them with
+ *                         milzma_move_units or keep out_off and raise out_cap when the room behind the slice is free.  No byte is
+ *                         decoded twice.  The input (d_in, in_off, in_len) must be what it was.
+ * Parked states live until the next decode call on the context that is not a RESUME. */
+#define MILZMA_DECODE_GROW 1u
+#define MILZMA_DECODE_RESUME 2u
+int milzma_decode_units_ex(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_in,
+                           void *d_out, milzma_result *results, void *hip_stream, uint32_t flags);
+
+/* Device-side move of n byte ranges: d_dst[dst_off[i], +len[i]) = d_src[src_off[i], +len[i]) for all i in one launch (ranges of one
+ * call must not overlap each other's destination).  What a caller of MILZMA_DECODE_RESUME uses to carry the parked units' output
+ * into their larger slices; runs on hip_stream and returns when it has finished. */
+int milzma_move_units(milzma_ctx *ctx, uint32_t n, const void *d_src, const uint64_t *src_off,
+                      void *d_dst, const uint64_t *dst_off, const uint64_t *len, void *hip_stream);
 
 /* Same, with host-resident input / output: the library stages both through device buffers it
  * owns (PCIe-inclusive path).  Every unit's slices are checked against in_bytes / out_bytes and
@@ -184,7 +216,14 @@ typedef struct milzma_output {
 } milzma_output;
 
 void milzma_default_options(milzma_options *opt);
+/* Returns an output buffer (milzma_output.data) to the library.  The library keeps a registry of the pointers it has handed out:
+ * a pointer that is not in it (foreign, or freed already) is ignored WITHOUT being dereferenced.  Freed buffers rest in a
+ * process-wide pool and are handed out again by later calls (their pages stay mapped: a batch call hands out thousands of buffers);
+ * the pool holds at most what the caller had in use at once, and never more than MILZMA_POOL_BYTES (environment, default 8 GiB). */
 void milzma_free(void *p);
+/* Gives pooled output buffers back to the C allocator until at most keep_bytes rest in the pool (0: all of them), and forgets the
+ * high-water mark that bounds what the pool keeps.  Returns the bytes still pooled.  Thread-safe; needs no context. */
+size_t milzma_pool_trim(size_t keep_bytes);
 
 /* lzma_decompress_with_options (src/lib.rs:52-60); opt == NULL => Options::default() */
 int milzma_lzma_decompress(milzma_ctx *ctx, const uint8_t *in, size_t in_len,

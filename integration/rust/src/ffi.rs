@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_float, c_int, c_void};
 
-pub const MILZMA_ABI_VERSION: u32 = 2;
+pub const MILZMA_ABI_VERSION: u32 = 3;
 
 // error kinds: error::Error variants (src/error.rs:8-17)
 pub const MILZMA_OK: c_int = 0;
@@ -27,6 +27,10 @@ pub const MILZMA_USE_PROVIDED: i32 = 2;
 
 pub const MILZMA_ST_OK: u32 = 0;
 pub const MILZMA_ST_OUT_FULL: u32 = 32;
+/// `milzma_result.err_a` of a unit that stopped for room and can be resumed (MILZMA_DECODE_RESUME)
+pub const MILZMA_PARKED: u64 = 1;
+pub const MILZMA_DECODE_GROW: u32 = 1;
+pub const MILZMA_DECODE_RESUME: u32 = 2;
 
 /// One independent serial decode job (one wavefront).
 #[repr(C)]
@@ -114,6 +118,27 @@ extern "C" {
         hip_stream: *mut c_void,
     ) -> c_int;
     pub fn milzma_decode_units_wait(ctx: *mut milzma_ctx, results: *mut milzma_result) -> c_int;
+    /// growable output: MILZMA_DECODE_GROW parks units that run out of room, MILZMA_DECODE_RESUME continues them in larger slices
+    pub fn milzma_decode_units_ex(
+        ctx: *mut milzma_ctx,
+        units: *const milzma_unit,
+        n: u32,
+        d_in: *const c_void,
+        d_out: *mut c_void,
+        results: *mut milzma_result,
+        hip_stream: *mut c_void,
+        flags: u32,
+    ) -> c_int;
+    pub fn milzma_move_units(
+        ctx: *mut milzma_ctx,
+        n: u32,
+        d_src: *const c_void,
+        src_off: *const u64,
+        d_dst: *mut c_void,
+        dst_off: *const u64,
+        len: *const u64,
+        hip_stream: *mut c_void,
+    ) -> c_int;
     pub fn milzma_decode_units_host(
         ctx: *mut milzma_ctx,
         units: *const milzma_unit,
@@ -139,6 +164,7 @@ extern "C" {
 
     pub fn milzma_default_options(opt: *mut milzma_options);
     pub fn milzma_free(p: *mut c_void);
+    pub fn milzma_pool_trim(keep_bytes: usize) -> usize;
 
     pub fn milzma_lzma_decompress(
         ctx: *mut milzma_ctx,

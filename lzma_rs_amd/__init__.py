@@ -34,6 +34,8 @@ SIZE_UNKNOWN = 0xFFFFFFFFFFFFFFFF
 NO_LIMIT = 0xFFFFFFFFFFFFFFFF
 ST_OK = 0
 ST_OUT_FULL = 32
+PARKED = 1                      # Result.err_a of a unit that stopped for room and can be resumed (MILZMA_PARKED)
+DECODE_GROW, DECODE_RESUME = 1, 2   # flags of decode_units_ex (MILZMA_DECODE_*)
 
 
 class Error(Exception):
@@ -143,6 +145,7 @@ EXPORTS = [
     "milzma_multi_lzma_decompress_batch", "milzma_multi_lzma2_decompress_batch", "milzma_multi_xz_decompress_batch",
     "milzma_lzma_decompress_batch_async", "milzma_lzma2_decompress_batch_async", "milzma_xz_decompress_batch_async",
     "milzma_batch_wait",
+    "milzma_decode_units_ex", "milzma_move_units", "milzma_pool_trim",
 ]
 
 _lib = None
@@ -172,6 +175,10 @@ def lib():
     L.milzma_last_error.restype = ctypes.c_char_p
     L.milzma_last_error.argtypes = [vp]
     L.milzma_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result), vp]
+    L.milzma_decode_units_ex.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result), vp, u32]
+    L.milzma_move_units.argtypes = [vp, u32, vp, ctypes.POINTER(u64), vp, ctypes.POINTER(u64), ctypes.POINTER(u64), vp]
+    L.milzma_pool_trim.restype = sz
+    L.milzma_pool_trim.argtypes = [sz]
     L.milzma_decode_units_async.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, vp, vp]
     L.milzma_decode_units_wait.argtypes = [vp, ctypes.POINTER(Result)]
     L.milzma_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz,
@@ -307,6 +314,30 @@ class Context:
         ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
         return results, ms, launches.value
 
+    def decode_units_ex(self, units, d_in, d_out, flags, results=None, stream=0):
+        """milzma_decode_units_ex: DECODE_GROW parks units that run out of room (Result.status == ST_OUT_FULL, err_a == PARKED);
+        DECODE_RESUME (with the previous call's `results`) continues them in their new, larger slices.
+        Returns (results, kernel_ms, launches); `results` is updated in place when given."""
+        n = len(units)
+        if results is None:
+            results = (Result * n)()
+        r = lib().milzma_decode_units_ex(self._h, units, n, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), results,
+                                         ctypes.c_void_p(stream), flags)
+        if r != OK:
+            raise InfraError("milzma_decode_units_ex: " + self.last_error())
+        launches = ctypes.c_uint32()
+        ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
+        return results, ms, launches.value
+
+    def move_units(self, d_src, src_off, d_dst, dst_off, lens, stream=0):
+        """milzma_move_units: d_dst[dst_off[i], +lens[i]) = d_src[src_off[i], +lens[i]) on the device, one launch."""
+        n = len(lens)
+        A = ctypes.c_uint64 * n
+        r = lib().milzma_move_units(self._h, n, ctypes.c_void_p(d_src), A(*src_off), ctypes.c_void_p(d_dst), A(*dst_off), A(*lens),
+                                    ctypes.c_void_p(stream))
+        if r != OK:
+            raise InfraError("milzma_move_units: " + self.last_error())
+
     def decode_units_async(self, units, d_in, d_out, stream=0):
         """Enqueue only (milzma_decode_units_async); finish with decode_units_wait(len(units))."""
         r = lib().milzma_decode_units_async(self._h, units, len(units), ctypes.c_void_p(d_in), ctypes.c_void_p(d_out),
@@ -375,10 +406,13 @@ class Context:
         outs = (_COutput * n)()
         if with_options:
             o = _c_options(options)
-            fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
+            rc = fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
         else:
-            fn(self._h, n, ptrs, lens, outs)
-        return [Decoded(outs[i]) for i in range(n)]
+            rc = fn(self._h, n, ptrs, lens, outs)
+        decs = [Decoded(outs[i]) for i in range(n)]   # (also hands the buffers of a failed call back)
+        if rc != OK:                                  # an infrastructure failure of the call itself, as batch_wait reports it
+            raise InfraError("batch call failed: " + self.last_error())
+        return decs
 
     def lzma_batch(self, datas, options=None):
         return self._batch(lib().milzma_lzma_decompress_batch, datas, options, True)
@@ -493,10 +527,13 @@ class MultiContext:
         outs = (_COutput * n)()
         if with_options:
             o = _c_options(options)
-            fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
+            rc = fn(self._h, n, ptrs, lens, ctypes.byref(o), outs)
         else:
-            fn(self._h, n, ptrs, lens, outs)
-        return [Decoded(outs[i]) for i in range(n)]
+            rc = fn(self._h, n, ptrs, lens, outs)
+        decs = [Decoded(outs[i]) for i in range(n)]
+        if rc != OK:   # (never a list of empty successes: the library fills every slot, and the call's failure is raised)
+            raise InfraError("multi batch call failed: " + self.last_error())
+        return decs
 
     def lzma_batch(self, datas, options=None):
         return self._batch(lib().milzma_multi_lzma_decompress_batch, datas, options, True)

@@ -16,10 +16,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "kernels.h"
@@ -55,7 +57,7 @@ struct UploadTurn {  // whose upload may use the PCIe link now: groups of one ca
 struct milzma_ctx {
   int device = 0;
   std::string err;
-  DevBuf units, order, results, scratch, in, out, crc, flags, slice_q, slice_ctx;  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
+  DevBuf units, order, results, scratch, in, out, pack, crc, flags, slice_q, slice_ctx;  // pack: finished outputs gathered for the download  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
   PinBuf pin_in, pin_out, pin_small;
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -68,6 +70,11 @@ struct milzma_ctx {
   const uint8_t* pend_in = nullptr;
   uint8_t* pend_out = nullptr;
   std::vector<milzma_unit> pend_units;  // (the caller's array need not outlive the call)
+  uint32_t pend_flags = 0;              // MILZMA_DECODE_* of the batch in flight
+  // growable output (milzma_decode_units_ex): the last GROW / RESUME call left units parked in slice_ctx (indexed by unit: the next
+  // call may resume them as long as it is a RESUME with the same n); any other decode call on the context gives the parking lot up
+  bool parked_valid = false;
+  uint32_t parked_n = 0;
   PinBuf pin_results;
   hipStream_t copy_stream = nullptr;    // chunked staging copies of the whole-file batch entry points
   hipStream_t work_stream = nullptr;    // decode launches of the whole-file / host-buffer entry points: the context's own
@@ -326,6 +333,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   dev_release(ctx->scratch);
   dev_release(ctx->in);
   dev_release(ctx->out);
+  dev_release(ctx->pack);
   dev_release(ctx->crc);
   dev_release(ctx->flags);
   dev_release(ctx->slice_q);
@@ -354,30 +362,42 @@ extern "C" float milzma_last_kernel_ms(const milzma_ctx* ctx, uint32_t* launches
 // ---- output buffers: a pool behind out_set_data / milzma_free --------------------------------------------------------
 // A batch call hands back thousands of MiB-sized buffers.  Fresh from malloc each is its own mmap: a million page faults per
 // 4 GiB call (and as many munmaps when the caller frees them), all serialised on the process's mmap lock -- a third of
-// the call's host time.  Buffers freed with milzma_free are kept (by size class, up to MILZMA_POOL_BYTES, default 8 GiB) and
-// handed out again with their pages already mapped.
+// the call's host time.  Buffers freed with milzma_free are kept by size class and handed out again with their pages already
+// mapped.  What the pool may hold: never more than the caller had handed out at once (the high-water mark of live bytes, so a
+// process that decodes 64 MiB at a time keeps 64 MiB), never more than MILZMA_POOL_BYTES (default 8 GiB); milzma_pool_trim
+// gives memory back on request.  Every pointer handed out is registered: milzma_free looks a pointer up instead of reading the
+// bytes in front of it, so a foreign pointer (or one freed twice) is recognised without being dereferenced.
 namespace {
 
 struct OutHdr {
-  uint64_t magic;
   uint64_t cap;
+  uint64_t pad;  // (keeps the payload 16-byte aligned)
 };
-constexpr uint64_t kOutMagic = 0x6D696C7A6D61504Full;    // "milzmaPO": handed out
-constexpr uint64_t kOutPooled = 0x6D696C7A6D61506Full;   // resting in the pool (a second milzma_free of the same pointer is ignored)
 
 struct OutPool {
   std::mutex mu;
-  std::unordered_map<size_t, std::vector<OutHdr*>> free_by_cap;
-  size_t held = 0, limit = size_t(8) << 30;
+  std::map<size_t, std::vector<OutHdr*>> free_by_cap;   // ordered: a request takes the smallest class that holds it
+  std::unordered_set<const void*> live;                  // payload pointers handed out and not yet freed
+  size_t held = 0, live_bytes = 0, peak_live = 0, limit = size_t(8) << 30;
   OutPool() {
     if (const char* e = getenv("MILZMA_POOL_BYTES")) limit = size_t(strtoull(e, nullptr, 0));
   }
   ~OutPool() {
     for (auto& kv : free_by_cap)
-      for (OutHdr* h : kv.second) {
-        h->magic = 0;
+      for (OutHdr* h : kv.second) free(h);
+  }
+  // (mu held) frees pooled buffers, largest classes first, until at most `keep` bytes rest in the pool
+  void trim_locked(size_t keep) {
+    for (auto it = free_by_cap.end(); held > keep && it != free_by_cap.begin();) {
+      --it;
+      while (held > keep && !it->second.empty()) {
+        OutHdr* h = it->second.back();
+        it->second.pop_back();
+        held -= size_t(h->cap);
         free(h);
       }
+      if (it->second.empty()) it = free_by_cap.erase(it);
+    }
   }
 };
 OutPool& out_pool() {
@@ -398,21 +418,31 @@ size_t out_class(size_t n) {  // capacity class: powers of two up to 64 KiB, mul
 uint8_t* out_alloc(size_t n) {
   const size_t cap = out_class(n);
   OutPool& p = out_pool();
-  {
+  OutHdr* h = nullptr;
+  try {
     std::lock_guard<std::mutex> lock(p.mu);
-    auto it = p.free_by_cap.find(cap);
-    if (it != p.free_by_cap.end() && !it->second.empty()) {
-      OutHdr* h = it->second.back();
+    // best fit: the smallest pooled class that holds the request, as long as it wastes at most half of itself (a workload of
+    // varied sizes reuses what it has instead of filling the pool with classes that never match exactly)
+    auto it = p.free_by_cap.lower_bound(cap);
+    while (it != p.free_by_cap.end() && it->second.empty()) it = p.free_by_cap.erase(it);
+    if (it != p.free_by_cap.end() && it->first <= std::max(cap * 2, cap + (size_t(1) << 16))) {
+      h = it->second.back();
       it->second.pop_back();
-      p.held -= cap;
-      h->magic = kOutMagic;
-      return reinterpret_cast<uint8_t*>(h + 1);
+      p.held -= size_t(h->cap);
     }
+    if (!h) {
+      h = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
+      if (!h) return nullptr;
+      h->cap = cap;
+      h->pad = 0;
+    }
+    p.live.insert(h + 1);
+    p.live_bytes += size_t(h->cap);
+    p.peak_live = std::max(p.peak_live, p.live_bytes);
+  } catch (const std::bad_alloc&) {  // (the registry could not grow: the buffer is not handed out)
+    free(h);
+    return nullptr;
   }
-  auto* h = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
-  if (!h) return nullptr;
-  h->magic = kOutMagic;
-  h->cap = cap;
   return reinterpret_cast<uint8_t*>(h + 1);
 }
 
@@ -420,23 +450,33 @@ uint8_t* out_alloc(size_t n) {
 
 extern "C" void milzma_free(void* ptr) {
   if (!ptr) return;
-  OutHdr* h = static_cast<OutHdr*>(ptr) - 1;
-  if (h->magic != kOutMagic) return;  // not one of ours (or freed twice): leave it alone rather than corrupt the heap
   OutPool& p = out_pool();
+  OutHdr* h = nullptr;
   {
     std::lock_guard<std::mutex> lock(p.mu);
-    if (p.held + h->cap <= p.limit) {
+    const auto it = p.live.find(ptr);
+    if (it == p.live.end()) return;  // not handed out by this library, or freed already: never dereferenced, left alone
+    p.live.erase(it);
+    h = static_cast<OutHdr*>(ptr) - 1;
+    p.live_bytes -= size_t(h->cap);
+    if (p.held + h->cap <= std::min(p.limit, p.peak_live)) {
       try {
         p.free_by_cap[size_t(h->cap)].push_back(h);
         p.held += size_t(h->cap);
-        h->magic = kOutPooled;
         return;
       } catch (const std::bad_alloc&) {
       }
     }
   }
-  h->magic = 0;
   free(h);
+}
+
+extern "C" size_t milzma_pool_trim(size_t keep_bytes) {
+  OutPool& p = out_pool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  p.trim_locked(keep_bytes);
+  p.peak_live = p.live_bytes;  // (the high-water mark starts over: the pool refills only as far as later calls go)
+  return p.held;
 }
 
 extern "C" void milzma_default_options(milzma_options* opt) {
@@ -459,7 +499,7 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   // switches to properties that class is not built for.
   if (u.kind != MILZMA_KIND_RAW_LZMA) return ctx->use_fast ? kFast : kLitLds3;
   const uint32_t lclp = uint32_t(u.lc) + u.lp;
-  if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return (u.pb > 2 && !fast8_takes_pb4()) ? kFastLc4 : kFast;
+  if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return kFast;
   if (ctx->use_fast && u.pb <= 4 && lclp == 4) return kFastLc4;
   if (lclp <= 3) return kLitLds3;
   if (lclp <= 4) return kLitLds4;
@@ -468,7 +508,7 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
 
 // Launches `order` (unit indices) in class `cls`; kernel time is accumulated into ctx.
 bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& order, uint32_t order_base,
-                  const uint8_t* d_in, uint8_t* d_out, hipStream_t stream) {
+                  const uint8_t* d_in, uint8_t* d_out, hipStream_t stream, bool grow = false, bool resume = false) {
   if (order.empty()) return true;
   auto* d_units = static_cast<const milzma_unit*>(ctx->units.p);
   auto* d_order = static_cast<const uint32_t*>(ctx->order.p) + order_base;
@@ -499,7 +539,8 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     uint32_t cap = 0;
     if (cls == kFast || cls == kFastLc4) {
       const uint32_t resident = fast_resident_blocks(cls == kFastLc4, ctx->lds_pad);
-      sliced = ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
+      // (growable output is a feature of the time-sliced kernel: it is the one that can park a unit)
+      sliced = grow || ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
       if (sliced) {
         uint64_t entries = m, longest = 0;
         const uint64_t least = std::max<uint32_t>(1u, ctx->slice_quantum / 4u * 3u);  // (a turn is 0.75 .. 1.5 quanta)
@@ -508,15 +549,19 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
           entries += cap_k / least + 2;
           longest = std::max(longest, cap_k);
         }
-        const size_t ctx_bytes = slice_ctx_bytes(cls == kFastLc4) * ctx->pend_n;  // (indexed by unit, not by launch position)
+        const size_t ctx_bytes = slice_ctx_bytes() * ctx->pend_n;  // (indexed by unit, not by launch position)
         size_t free_b = 0, total_b = 0;
         const std::string keep = ctx->err;
         // Not worth it / not to be had: units that all end within their first turn are never parked (the hardware's own block dispatch
         // does as well for them, without a parking lot of 20-34 KB per unit); a parking lot beyond a quarter of the free memory.
-        if ((ctx->slice_mode == 0 && longest <= least) || entries > 0x7FFFFFF0ull ||
+        if ((ctx->slice_mode == 0 && longest <= least && !grow) || entries > 0x7FFFFFF0ull ||
             (ctx_bytes > ctx->slice_ctx.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx_bytes > (free_b + ctx->slice_ctx.cap) / 4) ||
             !dev_reserve(ctx, ctx->slice_q, slice_queue_bytes(uint32_t(entries))) || !dev_reserve(ctx, ctx->slice_ctx, ctx_bytes)) {
           sliced = false;
+          if (resume) {  // (the parked states cannot be reached without it)
+            if (ctx->err.empty() || ctx->err == keep) ctx->err = "no memory for the time-sliced launch that resumes parked units";
+            return false;
+          }
           ctx->err = keep;
         }
         cap = uint32_t(entries);
@@ -525,7 +570,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     const hipError_t le = sliced
                               ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                                    static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
-                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p)
+                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow)
                           : cls == kFast || cls == kFastLc4
                               ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                             static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
@@ -556,8 +601,15 @@ bool collect_kernel_ms(milzma_ctx* ctx) {
 // Enqueue: descriptor upload, one launch per class, result download into a page-locked buffer -- all on `stream`,
 // nothing waits for the GPU.
 static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
-                                          void* d_out, void* hip_stream) {
+                                          void* d_out, void* hip_stream, uint32_t flags = 0, const milzma_result* prev = nullptr) {
   if (!ctx) return MILZMA_INFRA_ERROR;
+  const bool resume = (flags & MILZMA_DECODE_RESUME) != 0;
+  const bool grow = resume || (flags & MILZMA_DECODE_GROW) != 0;
+  if (resume && (!ctx->parked_valid || ctx->parked_n != n || !prev)) {
+    ctx->err = "MILZMA_DECODE_RESUME: this context holds no parked units of a batch of that size";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (!resume) ctx->parked_valid = false;  // (whatever was parked here is given up: the parking lot serves this batch now)
   if (ctx->pending) {
     ctx->err = "a batch is already in flight on this context: call milzma_decode_units_wait first";
     return MILZMA_INFRA_ERROR;
@@ -570,6 +622,7 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   ctx->last_launches = 0;
   ctx->ev_used = 0;
   ctx->pend_n = n;
+  ctx->pend_flags = (grow ? MILZMA_DECODE_GROW : 0u) | (resume ? MILZMA_DECODE_RESUME : 0u);
   ctx->pending = true;
   if (n == 0) return MILZMA_OK;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -600,7 +653,12 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
   std::vector<uint32_t> order[kNumLitClasses];
-  for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
+  if (resume) {  // only what the previous call parked, each unit in the class it was parked in (err_b: the instantiation's rows)
+    for (uint32_t i = 0; i < n; i++)
+      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED) order[prev[i].err_b == 16 ? kFastLc4 : kFast].push_back(i);
+  } else {
+    for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
+  }
   std::vector<uint32_t> flat;
   flat.reserve(n);
   uint32_t base[kNumLitClasses];
@@ -642,15 +700,21 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
     return fail();
   // (the order array is staged in page-locked memory behind the results so that its upload is asynchronous too)
   uint32_t* h_order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->pin_results.p) + size_t(n) * sizeof(milzma_result));
-  memcpy(h_order, flat.data(), size_t(n) * sizeof(uint32_t));
+  for (size_t k = 0; k < flat.size(); k++) h_order[k] = flat[k] | (resume ? 0x80000000u : 0u);  // (bit 31: resume from the parked state)
   if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
               "H2D units") ||
-      !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h_order, size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, stream),
-              "H2D order"))
+      (!flat.empty() &&
+       !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h_order, flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream), "H2D order")))
     return fail();
+  if (resume) {  // the units that are not resumed keep the results they have
+    memcpy(ctx->pin_results.p, prev, size_t(n) * sizeof(milzma_result));
+    if (!hip_ok(ctx, hipMemcpyAsync(ctx->results.p, ctx->pin_results.p, size_t(n) * sizeof(milzma_result), hipMemcpyHostToDevice, stream),
+                "H2D results"))
+      return fail();
+  }
 
   for (int c = 0; c < kNumLitClasses; c++)
-    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream)) return fail();
+    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream, grow, resume)) return fail();
 
   // (The results are fetched by the wait half, after the kernels: a copy queued behind a running kernel parks a DMA queue on
   //  that kernel's completion, and an unrelated upload of another context that lands on the same queue then waits for the whole
@@ -699,24 +763,32 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
                 "H2D order") ||
         !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))  // (`again` is pageable and about to go away)
       return MILZMA_INFRA_ERROR;
-    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream)) return MILZMA_INFRA_ERROR;
+    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream, (ctx->pend_flags & MILZMA_DECODE_GROW) != 0)) return MILZMA_INFRA_ERROR;
     if (!hip_ok(ctx,
                 hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
                 "D2H results") ||
         !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") || !collect_kernel_ms(ctx))
       return MILZMA_INFRA_ERROR;
   }
+  if (ctx->pend_flags & MILZMA_DECODE_GROW) {
+    bool any = false;
+    for (uint32_t i = 0; i < n && !any; i++) any = results[i].status == MILZMA_ST_OUT_FULL && results[i].err_a == MILZMA_PARKED;
+    ctx->parked_valid = any;
+    ctx->parked_n = n;
+  }
   return MILZMA_OK;
 }
 
 static int milzma_decode_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
-                                   void* d_out, milzma_result* results, void* hip_stream) {
+                                   void* d_out, milzma_result* results, void* hip_stream, uint32_t flags = 0) {
   if (!ctx) return MILZMA_INFRA_ERROR;
   if (n && !results) {
     ctx->err = "null units/results";
     return MILZMA_INFRA_ERROR;
   }
-  const int r = milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream);
+  std::vector<milzma_result> prev;  // (a RESUME reads the previous results and then writes the same array)
+  if ((flags & MILZMA_DECODE_RESUME) && n) prev.assign(results, results + n);
+  const int r = milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream, flags, prev.empty() ? nullptr : prev.data());
   return r != MILZMA_OK ? r : milzma_decode_units_wait_impl(ctx, results);
 }
 
@@ -999,6 +1071,31 @@ extern "C" int milzma_crc_units(milzma_ctx* ctx, const milzma_unit* units, uint3
 // helpers shared by the whole-file entry points
 // ------------------------------------------------------------------------------------------
 
+// d_dst[dst_off[i], +len[i]) = d_src[src_off[i], +len[i]) on the device, one launch (milzma_move_units)
+static int move_units_impl(milzma_ctx* ctx, uint32_t n, const void* d_src, const uint64_t* src_off, void* d_dst, const uint64_t* dst_off,
+                           const uint64_t* len, hipStream_t stream) {
+  if (!ctx) return MILZMA_INFRA_ERROR;
+  if (n == 0) return MILZMA_OK;
+  if (!d_src || !d_dst || !src_off || !dst_off || !len) {
+    ctx->err = "null argument";
+    return MILZMA_INFRA_ERROR;
+  }
+  const size_t bytes = size_t(n) * 3 * sizeof(uint64_t);
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !dev_reserve(ctx, ctx->order, std::max(bytes, ctx->order.cap)) ||
+      !pin_reserve(ctx, ctx->pin_small, bytes))
+    return MILZMA_INFRA_ERROR;
+  uint64_t* h = static_cast<uint64_t*>(ctx->pin_small.p);
+  memcpy(h, src_off, size_t(n) * 8);
+  memcpy(h + n, dst_off, size_t(n) * 8);
+  memcpy(h + 2 * size_t(n), len, size_t(n) * 8);
+  if (!hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h, bytes, hipMemcpyHostToDevice, stream), "H2D move list") ||
+      !hip_ok(ctx, launch_move_units(static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), static_cast<const uint64_t*>(ctx->order.p), n, stream),
+              "move kernel launch") ||
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+    return MILZMA_INFRA_ERROR;
+  return MILZMA_OK;
+}
+
 namespace {
 
 struct Cursor {  // io::BufRead over a slice
@@ -1075,31 +1172,91 @@ int infra(milzma_ctx* ctx, milzma_output* o) {
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 size_t plan_budget(milzma_ctx* ctx);
 
-// One unit through the device with host buffers, growing the output slice while the kernel
-// reports OUT_FULL.  `cap_hint` is the first slice size to try.
+
+inline bool is_parked(const milzma_result& r) { return r.status == MILZMA_ST_OUT_FULL && r.err_a == MILZMA_PARKED; }
+
+// The next slice size for a unit that ran out of room: what its progress so far predicts for the whole stream (output per input
+// byte x the input that is left) plus an eighth, at least twice and at most sixteen times what it had.
+size_t grown_cap(const milzma_unit& u, const milzma_result& r) {
+  const long double rate = (long double)(r.out_len + 1) / (long double)std::max<uint64_t>(1, r.in_consumed);
+  const long double est = rate * (long double)u.in_len * 1.125L + 65536.0L;
+  uint64_t cap = est > 1e18L ? UINT64_MAX / 2 : uint64_t(est);
+  cap = std::max<uint64_t>(cap, 2 * u.out_cap + 4096);
+  cap = std::min<uint64_t>(cap, 16 * u.out_cap + (uint64_t(1) << 20));
+  return size_t(std::min<uint64_t>(round_up(size_t(cap), 256), MILZMA_MAX_UNIT_BYTES));
+}
+
+// Gives every unit of `parked` (indices into units / res: status PARKED) a larger slice in a FRESH output buffer, packed from offset
+// 0 in list order, and moves what it has produced there (its dictionary); ctx->out becomes that buffer.  Nothing may still be
+// reading the old one.  The descriptors are updated; the caller resumes the units with MILZMA_DECODE_RESUME.
+bool regrow_parked(milzma_ctx* ctx, std::vector<milzma_unit>& units, const std::vector<milzma_result>& res,
+                   const std::vector<uint32_t>& parked, hipStream_t ws, size_t* out_bytes) {
+  std::vector<uint64_t> so(parked.size()), dof(parked.size()), ln(parked.size());
+  std::vector<size_t> cap(parked.size());
+  size_t total = 0;
+  for (size_t j = 0; j < parked.size(); j++) {
+    const uint32_t k = parked[j];
+    cap[j] = grown_cap(units[k], res[k]);
+    so[j] = units[k].out_off;
+    dof[j] = total;
+    ln[j] = std::min<uint64_t>(res[k].out_len, units[k].out_cap);
+    total += cap[j];
+  }
+  DevBuf nb;
+  if (!dev_reserve(ctx, nb, total + 512)) return false;
+  if (move_units_impl(ctx, uint32_t(parked.size()), ctx->out.p, so.data(), nb.p, dof.data(), ln.data(), ws) != MILZMA_OK) {
+    dev_release(nb);
+    return false;
+  }
+  dev_release(ctx->out);
+  ctx->out = nb;
+  for (size_t j = 0; j < parked.size(); j++) {
+    units[parked[j]].out_off = dof[j];
+    units[parked[j]].out_cap = cap[j];
+  }
+  *out_bytes = total;
+  return true;
+}
+
+// One unit through the device with host buffers.  Its output slice grows while the stream needs more room: a unit of the fast
+// kernels is parked at the end of its slice and resumed in a larger one (nothing is decoded twice); a unit of the generic kernel
+// (lc + lp > 4) reports a plain OUT_FULL and starts over with four times the room.  `cap_hint` is the first slice size to try.
 struct SingleDecode {
   milzma_result res;
   std::vector<uint8_t> out;  // the unit's output slice (res.out_len bytes valid, capped by size)
 };
 
 bool decode_single(milzma_ctx* ctx, milzma_unit u, const uint8_t* in, size_t in_len, size_t cap_hint, SingleDecode* sd) {
+  if (!ctx) return false;
   size_t cap = std::max<size_t>(cap_hint, 4096);
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !dev_reserve(ctx, ctx->in, in_len + 512)) return false;
+  if (in_len && !hip_ok(ctx, hipMemcpy(ctx->in.p, in, in_len, hipMemcpyHostToDevice), "H2D input")) return false;
+  std::vector<milzma_unit> units(1);
+  std::vector<milzma_result> res(1);
+  const std::vector<uint32_t> one{0};
   for (;;) {
     cap = std::min<size_t>(round_up(cap, 256), MILZMA_MAX_UNIT_BYTES);
     u.in_off = 0;
     u.in_len = in_len;
     u.out_off = 0;
     u.out_cap = cap;
-    if (!ctx) return false;
-    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !dev_reserve(ctx, ctx->in, in_len + 512) ||
-        !dev_reserve(ctx, ctx->out, cap + 512))
-      return false;
-    if (in_len && !hip_ok(ctx, hipMemcpy(ctx->in.p, in, in_len, hipMemcpyHostToDevice), "H2D input")) return false;
-    if (milzma_decode_units(ctx, &u, 1, ctx->in.p, ctx->out.p, &sd->res, work_stream(ctx)) != MILZMA_OK) return false;
-    if (sd->res.status == MILZMA_ST_OUT_FULL && cap < MILZMA_MAX_UNIT_BYTES) {
-      cap = cap * 4;
+    units[0] = u;
+    if (!dev_reserve(ctx, ctx->out, cap + 512)) return false;
+    uint32_t flags = MILZMA_DECODE_GROW;
+    for (;;) {
+      if (milzma_decode_units_impl(ctx, units.data(), 1, ctx->in.p, ctx->out.p, res.data(), work_stream(ctx), flags) != MILZMA_OK) return false;
+      if (!is_parked(res[0]) || units[0].out_cap >= MILZMA_MAX_UNIT_BYTES) break;
+      size_t bytes = 0;
+      if (!regrow_parked(ctx, units, res, one, work_stream(ctx), &bytes)) return false;
+      flags = MILZMA_DECODE_RESUME;
+    }
+    sd->res = res[0];
+    cap = size_t(units[0].out_cap);
+    if (sd->res.status == MILZMA_ST_OUT_FULL && !is_parked(sd->res) && cap < MILZMA_MAX_UNIT_BYTES) {
+      cap = cap * 4;  // (not resumable: again from the first byte)
       continue;
     }
+    if (is_parked(sd->res)) sd->res.err_a = 0;  // (at the largest slice there is: an ordinary OUT_FULL for whoever renders it)
     const size_t got = size_t(std::min<uint64_t>(sd->res.out_len, cap));  // only what was decoded travels back
     try {
       sd->out.resize(got);
@@ -1293,50 +1450,132 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       return fail_all();
   }
   const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
-  // Rounds: units whose guessed output slice was too small (unknown-size streams) run again, together,
-  // with four times the room; the input stays on the device.
-  std::vector<uint32_t> todo(units.size());
-  for (size_t k = 0; k < units.size(); k++) todo[k] = uint32_t(k);
-  while (!todo.empty()) {
-    std::vector<milzma_unit> sub(todo.size());
-    size_t out_bytes = 0;
-    for (size_t j = 0; j < todo.size(); j++) {
-      sub[j] = units[todo[j]];
-      sub[j].out_off = out_bytes;
-      out_bytes += size_t(sub[j].out_cap);
+  // Rounds.  A unit whose guessed output slice was too small (unknown-size streams: every .lzma that liblzma writes) is PARKED at
+  // the end of its slice by the decode kernel, given a larger slice -- what it has produced moves there on the device -- and
+  // RESUMED: no byte is decoded twice (the reference streams such output through its ring, lzbuffer.rs:258-270).  Every round
+  // hands over the units that finished in it.  What cannot be parked (the generic kernel's units: lc + lp > 4) comes back with a
+  // plain OUT_FULL and is decoded again afterwards with four times the room; the input stays on the device throughout.
+  const uint32_t nu = uint32_t(units.size());
+  std::vector<milzma_result> res(nu);
+  std::vector<uint32_t> active(nu), restart;
+  for (uint32_t k = 0; k < nu; k++) active[k] = k;
+  size_t out_bytes = out_total;
+  const auto give_up = [&](const std::vector<uint32_t>& list) {
+    for (uint32_t k : list) infra(ctx, &outs[owner[k]]);
+  };
+  for (bool first = true; !active.empty(); first = false) {
+    std::vector<uint32_t> parked;
+    {
+      if (milzma_decode_units_impl(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), work_stream(ctx),
+                                   first ? MILZMA_DECODE_GROW : MILZMA_DECODE_RESUME) != MILZMA_OK) {
+        give_up(active);
+        give_up(restart);
+        finish_alone();
+        return MILZMA_INFRA_ERROR;
+      }
+      trace_mark(ctx, "decode: done");
+      // What finished travels back packed (an unknown-size stream's slice is a guess several times its output: the link should not
+      // carry the slack): the move kernel gathers the finished outputs into a second device buffer, that one comes back in chunks
+      // and a stream is handed over as soon as its bytes have arrived.  Where the slices are (nearly) full they go as they are.
+      std::vector<uint32_t> fin;
+      std::vector<uint64_t> so, dof, ln;
+      size_t packed = 0, slack = 0;
+      for (uint32_t k : active) {
+        const milzma_result& r = res[k];
+        if (is_parked(r) && units[k].out_cap < MILZMA_MAX_UNIT_BYTES) {
+          parked.push_back(k);
+          continue;
+        }
+        if (r.status == MILZMA_ST_OUT_FULL && !is_parked(r) && units[k].out_cap < MILZMA_MAX_UNIT_BYTES) {
+          restart.push_back(k);
+          continue;
+        }
+        const uint64_t visible = std::min<uint64_t>(r.out_flushed, units[k].out_cap);
+        fin.push_back(k);
+        so.push_back(units[k].out_off);
+        dof.push_back(packed);
+        ln.push_back(visible);
+        packed += round_up(size_t(visible), 256);
+        slack += size_t(units[k].out_cap);
+      }
+      ChunkedCopy d2h;
+      const bool pack = !fin.empty() && slack > packed + packed / 8 + (size_t(1) << 20);
+      const uint8_t* hout = nullptr;
+      bool ok = true;
+      if (pack) {
+        ok = dev_reserve(ctx, ctx->pack, packed + 512) && pin_reserve(ctx, ctx->pin_out, packed) &&
+             move_units_impl(ctx, uint32_t(fin.size()), ctx->out.p, so.data(), ctx->pack.p, dof.data(), ln.data(), work_stream(ctx)) == MILZMA_OK &&
+             d2h.start_d2h(ctx, ctx->pin_out.p, ctx->pack.p, packed);
+      } else if (!fin.empty()) {
+        ok = pin_reserve(ctx, ctx->pin_out, out_bytes) && d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes);
+      }
+      if (!ok) {
+        give_up(fin);
+        give_up(parked);
+        give_up(restart);
+        finish_alone();
+        return MILZMA_INFRA_ERROR;
+      }
+      hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+      parallel_for(fin.size(), [&](size_t j) {
+        const uint32_t k = fin[j], i = owner[k];
+        const size_t off = pack ? size_t(dof[j]) : size_t(units[k].out_off);
+        if (!d2h.wait_until(off + size_t(ln[j]))) {
+          out_fail(&outs[i], MILZMA_INFRA_ERROR, "D2H output failed");
+          return;
+        }
+        milzma_result r = res[k];
+        if (is_parked(r)) r.err_a = 0;  // (at the largest slice there is: an ordinary OUT_FULL)
+        finish_stream(r, kind, hout + off, size_t(ln[j]), hdr[i], &outs[i]);
+      });
+      trace_mark(ctx, "download + hand-over: done");
+    }  // (the chunked copy has drained here: nothing reads ctx->out any more)
+    if (!parked.empty() && !regrow_parked(ctx, units, res, parked, work_stream(ctx), &out_bytes)) {
+      give_up(parked);
+      give_up(restart);
+      finish_alone();
+      return MILZMA_INFRA_ERROR;
+    }
+    active.swap(parked);
+  }
+  // the units that could not be parked: again from their first byte, together, with four times the room (rounds as before)
+  while (!restart.empty()) {
+    std::vector<milzma_unit> sub(restart.size());
+    size_t bytes = 0;
+    for (size_t j = 0; j < restart.size(); j++) {
+      milzma_unit& u = units[restart[j]];
+      u.out_cap = std::min<uint64_t>(round_up(size_t(u.out_cap) * 4, 256), MILZMA_MAX_UNIT_BYTES);
+      sub[j] = u;
+      sub[j].out_off = bytes;
+      bytes += size_t(sub[j].out_cap);
     }
     std::vector<milzma_result> r(sub.size());
-    ChunkedCopy d2h;  // the output comes back in chunks; a stream is handed over as soon as its slice has arrived
-    if (!pin_reserve(ctx, ctx->pin_out, out_bytes) || !dev_reserve(ctx, ctx->out, out_bytes + 512) ||
-        milzma_decode_units(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), work_stream(ctx)) != MILZMA_OK ||
-        (trace_mark(ctx, "decode: done"), !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, out_bytes))) {
-      for (uint32_t k : todo) infra(ctx, &outs[owner[k]]);
+    ChunkedCopy d2h;
+    if (!pin_reserve(ctx, ctx->pin_out, bytes) || !dev_reserve(ctx, ctx->out, bytes + 512) ||
+        milzma_decode_units_impl(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), work_stream(ctx), 0) != MILZMA_OK ||
+        !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, bytes)) {
+      give_up(restart);
       finish_alone();
       return MILZMA_INFRA_ERROR;
     }
     const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+    std::vector<uint32_t> next;
     std::vector<uint8_t> again(sub.size(), 0);
     parallel_for(sub.size(), [&](size_t j) {
       if (r[j].status == MILZMA_ST_OUT_FULL && sub[j].out_cap < MILZMA_MAX_UNIT_BYTES) {
         again[j] = 1;
         return;
       }
-      const uint32_t i = owner[todo[j]];
+      const uint32_t i = owner[restart[j]];
       if (!d2h.wait_until(size_t(sub[j].out_off + sub[j].out_cap))) {
         out_fail(&outs[i], MILZMA_INFRA_ERROR, "D2H output failed");
         return;
       }
       finish_stream(r[j], kind, hout + sub[j].out_off, size_t(sub[j].out_cap), hdr[i], &outs[i]);
     });
-    trace_mark(ctx, "download + hand-over: done");
-    std::vector<uint32_t> next;
     for (size_t j = 0; j < sub.size(); j++)
-      if (again[j]) {
-        milzma_unit& u = units[todo[j]];
-        u.out_cap = std::min<uint64_t>(round_up(size_t(u.out_cap) * 4, 256), MILZMA_MAX_UNIT_BYTES);
-        next.push_back(todo[j]);
-      }
-    todo.swap(next);
+      if (again[j]) next.push_back(restart[j]);
+    restart.swap(next);
   }
   return finish_alone();
 }
@@ -1890,8 +2129,14 @@ extern "C" int milzma_xz_decompress(milzma_ctx* ctx, const uint8_t* in, size_t i
   return r != MILZMA_OK ? r : out->kind;
 }
 
+// (every public call starts with an empty error text: what milzma_last_error returns afterwards belongs to THIS call)
+static inline void begin_call(milzma_ctx* ctx) {
+  if (ctx) ctx->err.clear();
+}
+
 extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
                                    void* d_out, milzma_result* results, void* hip_stream) {
+  begin_call(ctx);
   try {
     return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
@@ -1901,8 +2146,36 @@ extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, ui
   }
 }
 
+extern "C" int milzma_decode_units_ex(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in, void* d_out,
+                                      milzma_result* results, void* hip_stream, uint32_t flags) {
+  begin_call(ctx);
+  try {
+    if (ctx && (flags & ~(MILZMA_DECODE_GROW | MILZMA_DECODE_RESUME))) {
+      ctx->err = "unknown flags";
+      return MILZMA_INFRA_ERROR;
+    }
+    return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream, flags);
+  } catch (const std::exception& e) {
+    if (ctx) ctx->pending = false;
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_move_units(milzma_ctx* ctx, uint32_t n, const void* d_src, const uint64_t* src_off, void* d_dst,
+                                 const uint64_t* dst_off, const uint64_t* len, void* hip_stream) {
+  begin_call(ctx);
+  try {
+    return move_units_impl(ctx, n, d_src, src_off, d_dst, dst_off, len, static_cast<hipStream_t>(hip_stream));
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
 extern "C" int milzma_decode_units_host(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* h_in,
                                         size_t in_bytes, void* h_out, size_t out_bytes, milzma_result* results) {
+  begin_call(ctx);
   try {
     return milzma_decode_units_host_impl(ctx, units, n, h_in, in_bytes, h_out, out_bytes, results);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
@@ -1913,6 +2186,7 @@ extern "C" int milzma_decode_units_host(milzma_ctx* ctx, const milzma_unit* unit
 
 extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const milzma_options* opt,
                                       milzma_output* out) {
+  begin_call(ctx);
   try {
     return milzma_lzma_decompress_impl(ctx, in, in_len, opt, out);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
@@ -1923,6 +2197,7 @@ extern "C" int milzma_lzma_decompress(milzma_ctx* ctx, const uint8_t* in, size_t
 }
 
 extern "C" int milzma_lzma2_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
+  begin_call(ctx);
   try {
     return milzma_lzma2_decompress_impl(ctx, in, in_len, out);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
@@ -1990,34 +2265,46 @@ int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const 
   UploadTurn turn;
   std::vector<std::thread> th;
   std::vector<int> rc(nl, MILZMA_OK);
-  for (size_t k = 0; k < nl; k++)
-    th.emplace_back([&, k] {
-      milzma_ctx* lane = k ? ctx->lanes[k - 1] : ctx;
-      lane->turn = &turn;
-      lane->budget_share = uint32_t(nl);
-      for (size_t g = k; g < groups; g += nl) {
-        lane->turn_no = uint32_t(g);
-        lane->turn_done = false;
-        const uint32_t lo = cut[g], m = cut[g + 1] - cut[g];
-        int r = MILZMA_INFRA_ERROR;
-        try {
-          r = call(lane, m, ins + lo, in_lens + lo, outs + lo);
-        } catch (const std::exception& e) {
-          lane->err = std::string("host exception: ") + e.what();
-          for (uint32_t i = lo; i < lo + m; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
-        }
-        turn_release(lane);  // (a group that never reached its upload must not hold up the ones behind it)
-        if (r != MILZMA_OK) rc[k] = r;
+  const auto lane_body = [&](size_t k) {
+    milzma_ctx* lane = k ? ctx->lanes[k - 1] : ctx;
+    lane->turn = &turn;
+    lane->budget_share = uint32_t(nl);
+    for (size_t g = k; g < groups; g += nl) {
+      lane->turn_no = uint32_t(g);
+      lane->turn_done = false;
+      const uint32_t lo = cut[g], m = cut[g + 1] - cut[g];
+      int r = MILZMA_INFRA_ERROR;
+      try {
+        r = call(lane, m, ins + lo, in_lens + lo, outs + lo);
+      } catch (const std::exception& e) {
+        lane->err = std::string("host exception: ") + e.what();
+        for (uint32_t i = lo; i < lo + m; i++) out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", e.what());
       }
-      lane->turn = nullptr;
-      lane->budget_share = 1;
-    });
+      turn_release(lane);  // (a group that never reached its upload must not hold up the ones behind it)
+      if (r != MILZMA_OK) rc[k] = r;
+    }
+    lane->turn = nullptr;
+    lane->budget_share = 1;
+  };
+  // Lanes 1.. on threads of their own, lane 0 on the calling thread.  A thread that cannot be started (std::system_error) must not
+  // take the process down through the vector's destructor while its siblings run: the lanes that did start are joined, and the
+  // groups of the ones that did not are run here, one after the other.
+  std::vector<size_t> not_started;
+  for (size_t k = 1; k < nl; k++) {
+    try {
+      th.emplace_back(lane_body, k);
+    } catch (const std::exception&) {
+      not_started.push_back(k);
+    }
+  }
+  lane_body(0);
   for (auto& t : th) t.join();
+  for (size_t k : not_started) lane_body(k);
   int worst = MILZMA_OK;
   for (size_t k = 0; k < nl; k++)
     if (rc[k] != MILZMA_OK) {
       worst = rc[k];
-      if (k && ctx->err.empty()) ctx->err = ctx->lanes[k - 1]->err;
+      if (k) ctx->err = "lane " + std::to_string(k) + ": " + ctx->lanes[k - 1]->err;  // (always the failing lane's text, never a stale one)
     }
   return worst;
 }
@@ -2031,6 +2318,7 @@ uint32_t xz_units_of(const uint8_t* in, size_t n) {
 
 extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                             const milzma_options* opt, milzma_output* outs) {
+  begin_call(ctx);
   try {
     return grouped_batch(
         ctx, n, ins, in_lens, outs, [](uint32_t) { return 1u; },
@@ -2046,6 +2334,7 @@ extern "C" int milzma_lzma_decompress_batch(milzma_ctx* ctx, uint32_t n, const u
 
 extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                              milzma_output* outs) {
+  begin_call(ctx);
   try {
     return grouped_batch(
         ctx, n, ins, in_lens, outs, [](uint32_t) { return 1u; },
@@ -2061,6 +2350,7 @@ extern "C" int milzma_lzma2_decompress_batch(milzma_ctx* ctx, uint32_t n, const 
 
 extern "C" int milzma_xz_decompress_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                           milzma_output* outs) {
+  begin_call(ctx);
   try {
     return grouped_batch(
         ctx, n, ins, in_lens, outs, [&](uint32_t i) { return xz_units_of(ins[i], in_lens[i]); },
@@ -2172,6 +2462,7 @@ extern "C" int milzma_xz_plan(const uint8_t* in, size_t in_len, milzma_unit* uni
 
 extern "C" int milzma_decode_units_async(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in, void* d_out,
                                          void* hip_stream) {
+  begin_call(ctx);
   try {
     return milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream);
   } catch (const std::exception& e) {
@@ -2242,13 +2533,30 @@ int partition_impl(const uint64_t* weights, const uint32_t* group, uint32_t n, u
   return MILZMA_OK;
 }
 
-// runs fn(k) for every device index k on its own thread (the calling thread takes the last one)
-template <class F>
-void per_device(size_t nd, F fn) {
+// runs fn(k) for every device index k on its own thread (the calling thread takes the last one).  Nothing thrown on a worker leaves
+// it (an exception that escapes a std::thread is std::terminate, through the C ABI): failed(k, what) records it instead; a worker
+// that cannot be started runs on the calling thread after the others.
+template <class F, class G>
+void per_device(size_t nd, F fn, G failed) {
+  const auto guarded = [&](size_t k) {
+    try {
+      fn(k);
+    } catch (const std::exception& e) {
+      failed(k, e.what());
+    }
+  };
   std::vector<std::thread> th;
-  for (size_t k = 0; k + 1 < nd; k++) th.emplace_back([=] { fn(k); });
-  if (nd) fn(nd - 1);
+  std::vector<size_t> not_started;
+  for (size_t k = 0; k + 1 < nd; k++) {
+    try {
+      th.emplace_back(guarded, k);
+    } catch (const std::exception&) {
+      not_started.push_back(k);
+    }
+  }
+  if (nd) guarded(nd - 1);
   for (auto& t : th) t.join();
+  for (size_t k : not_started) guarded(k);
 }
 
 int multi_fail(milzma_multi* m, const std::string& why) {
@@ -2257,35 +2565,72 @@ int multi_fail(milzma_multi* m, const std::string& why) {
 }
 
 // Whole-file batch over the devices: files partitioned by size, each device runs the single-device entry point on its share.
+// every file that holds no result gets the infrastructure error (never left as the caller's zeroed "empty success")
+void multi_outs_fail(uint32_t n, milzma_output* outs, const uint8_t* has_result, const char* why) {
+  if (!outs) return;
+  for (uint32_t i = 0; i < n; i++) {
+    if (has_result && has_result[i]) continue;
+    out_reset(&outs[i]);
+    out_fail(&outs[i], MILZMA_INFRA_ERROR, "%s", why);
+  }
+}
+
 template <class Call>
 int multi_file_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, milzma_output* outs, Call call) {
-  if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  if (!m || m->ctx.empty()) {
+    multi_outs_fail(n, outs, nullptr, "no multi-device handle");
+    return MILZMA_INFRA_ERROR;
+  }
   if (n == 0) return MILZMA_OK;
-  if (!ins || !in_lens || !outs) return multi_fail(m, "null argument");
-  const uint32_t nd = uint32_t(m->ctx.size());
-  std::vector<uint64_t> w(n);
-  for (uint32_t i = 0; i < n; i++) w[i] = in_lens[i];
-  std::vector<uint32_t> part(n);
-  partition_impl(w.data(), nullptr, n, nd, part.data());
-  std::vector<std::vector<uint32_t>> share(nd);
-  for (uint32_t i = 0; i < n; i++) share[part[i]].push_back(i);
-  std::vector<int> rc(nd, MILZMA_OK);
-  per_device(nd, [&](size_t k) {
-    const std::vector<uint32_t>& idx = share[k];
-    if (idx.empty()) return;
-    std::vector<const uint8_t*> sub_in(idx.size());
-    std::vector<size_t> sub_len(idx.size());
-    std::vector<milzma_output> sub_out(idx.size());
-    for (size_t j = 0; j < idx.size(); j++) {
-      sub_in[j] = ins[idx[j]];
-      sub_len[j] = in_lens[idx[j]];
-    }
-    rc[k] = call(m->ctx[k], uint32_t(idx.size()), sub_in.data(), sub_len.data(), sub_out.data());
-    for (size_t j = 0; j < idx.size(); j++) outs[idx[j]] = sub_out[j];
-  });
-  for (uint32_t k = 0; k < nd; k++)
-    if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
-  return MILZMA_OK;
+  if (!ins || !in_lens || !outs) {
+    multi_outs_fail(n, outs, nullptr, "null argument");
+    return multi_fail(m, "null argument");
+  }
+  std::vector<uint8_t> has_result;
+  try {
+    has_result.assign(n, 0);
+    const uint32_t nd = uint32_t(m->ctx.size());
+    std::vector<uint64_t> w(n);
+    for (uint32_t i = 0; i < n; i++) w[i] = in_lens[i];
+    std::vector<uint32_t> part(n);
+    partition_impl(w.data(), nullptr, n, nd, part.data());
+    std::vector<std::vector<uint32_t>> share(nd);
+    for (uint32_t i = 0; i < n; i++) share[part[i]].push_back(i);
+    std::vector<int> rc(nd, MILZMA_OK);
+    per_device(
+        nd,
+        [&](size_t k) {
+          const std::vector<uint32_t>& idx = share[k];
+          if (idx.empty()) return;
+          std::vector<const uint8_t*> sub_in(idx.size());
+          std::vector<size_t> sub_len(idx.size());
+          std::vector<milzma_output> sub_out(idx.size());
+          for (size_t j = 0; j < idx.size(); j++) {
+            sub_in[j] = ins[idx[j]];
+            sub_len[j] = in_lens[idx[j]];
+          }
+          rc[k] = call(m->ctx[k], uint32_t(idx.size()), sub_in.data(), sub_len.data(), sub_out.data());
+          for (size_t j = 0; j < idx.size(); j++) {  // (the single-device calls fill every slot, also when they fail)
+            outs[idx[j]] = sub_out[j];
+            has_result[idx[j]] = 1;
+          }
+        },
+        [&](size_t k, const char* what) {
+          rc[k] = MILZMA_INFRA_ERROR;
+          m->ctx[k]->err = std::string("host exception: ") + what;
+        });
+    for (uint32_t k = 0; k < nd; k++)
+      if (rc[k] != MILZMA_OK) {
+        const std::string why = "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err;
+        multi_outs_fail(n, outs, has_result.data(), why.c_str());
+        return multi_fail(m, why);
+      }
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    const std::string why = std::string("host exception: ") + e.what();
+    multi_outs_fail(n, outs, has_result.empty() ? nullptr : has_result.data(), why.c_str());
+    return multi_fail(m, why);
+  }
 }
 
 }  // namespace
@@ -2390,6 +2735,9 @@ extern "C" int milzma_multi_decode_units(milzma_multi* m, const milzma_unit* uni
       rc[k] = milzma_decode_units(m->ctx[k], sub.data(), uint32_t(sub.size()), d_in[k], d_out[k], res.data(), nullptr);
       if (rc[k] == MILZMA_OK)
         for (size_t j = 0; j < idx.size(); j++) results[idx[j]] = res[j];
+    }, [&](size_t k, const char* what) {
+      rc[k] = MILZMA_INFRA_ERROR;
+      m->ctx[k]->err = std::string("host exception: ") + what;
     });
     for (uint32_t k = 0; k < nd; k++)
       if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
@@ -2487,6 +2835,9 @@ extern "C" int milzma_multi_decode_units_host(milzma_multi* m, const milzma_unit
       });
       for (uint8_t f : failed)
         if (f) return bad("D2H output failed");
+    }, [&](size_t k, const char* what) {
+      rc[k] = MILZMA_INFRA_ERROR;
+      m->ctx[k]->err = std::string("host exception: ") + what;
     });
     for (uint32_t k = 0; k < nd; k++)
       if (rc[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);

@@ -35,13 +35,16 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
 // bytes of output per turn and -- while other units wait (always_park: in any case, a testing mode) -- park the unit's state in
 // d_ctxmem (slice_ctx_bytes(lc4) per unit) and take the unit that has waited longest.
 uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad);
-// false in a build whose 8-row loop has no PB4 variant (five waves per SIMD): RAW units with pb 3 / 4 then start in the LC4 class
-bool fast8_takes_pb4();
-size_t slice_ctx_bytes(bool lc4);
+size_t slice_ctx_bytes();  // per unit, the same for both instantiations
 size_t slice_queue_bytes(uint32_t cap);
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem);
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow);
+// grow: growable output (milzma_decode_units_ex) -- a unit that runs out of room is parked in d_ctxmem with status OUT_FULL /
+// err_a = MILZMA_PARKED; d_order entries with bit 31 set resume such a unit (parked by an earlier launch with the same d_ctxmem)
+
+// d_offs: 3 n device words -- src_off[n], dst_off[n], len[n]
+hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream);
 
 // Partial CRCs (64 chunks per unit) of the units' decoded output; see crc_units.hip.h.
 struct CrcParts;

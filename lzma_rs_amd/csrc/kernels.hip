@@ -2,6 +2,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <mutex>
 
 #include "decode_generic.hip.h"
 #include "decode_fast_asm.hip.h"
@@ -37,25 +38,49 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
   return hipGetLastError();
 }
 
-// Blocks of the fast kernel the current device holds at once (occupancy API x CU count, asked once per instantiation;
-// the data-sheet figures -- 256 CUs x 16, or x 9 for the LC4 instantiation -- if the API fails).  Only decides whether the
-// priority rotation starts with the launch: a wrong value costs time, never correctness.
-uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad) {
-  static uint32_t cached[2] = {0, 0};
-  if (lds_pad == 0 && cached[lc4]) return cached[lc4];
-  uint32_t r = lc4 ? 256u * 9u : 256u * 16u;
-  int dev = 0, per_cu = 0;
+// Blocks of a fast kernel the CURRENT device holds at once: occupancy API x CU count, asked once per device and kernel (the cache
+// is keyed by the device ordinal and guarded: the lanes' and the multi-device workers' threads come through here concurrently, and
+// devices of one node may differ in CU count / partition mode); the data-sheet figures -- 256 CUs x 16, or x 12 for the LC4
+// instantiation -- if the API fails.  Decides when the priority rotation starts and how many persistent waves a time-sliced launch
+// gets: a wrong value costs time, never correctness.
+namespace {
+enum { kKernFast8 = 0, kKernFast16 = 1, kKernSliced8 = 2, kKernSliced16 = 3 };
+uint32_t resident_blocks(int kern, uint32_t lds_pad) {
+  static std::mutex mu;
+  static uint32_t cached[64][4] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = -1;
+  }
+  const bool cacheable = lds_pad == 0 && dev >= 0 && dev < 64;
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached[dev][kern]) return cached[dev][kern];
+  }
+  uint32_t r = (kern & 1) ? 256u * 12u : 256u * 16u;
+  int per_cu = 0;
   hipDeviceProp_t prop;
-  const hipError_t e = lc4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<16>, int(kWave), lds_pad)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<8>, int(kWave), lds_pad);
-  if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-      prop.multiProcessorCount > 0)
+  hipError_t e;
+  switch (kern) {
+    case kKernFast8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<8>, int(kWave), lds_pad); break;
+    case kKernFast16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<16>, int(kWave), lds_pad); break;
+    case kKernSliced8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<8>, int(kWave), lds_pad); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<16>, int(kWave), lds_pad); break;
+  }
+  if (e == hipSuccess && per_cu > 0 && dev >= 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     r = uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
   else
     (void)hipGetLastError();
-  if (lds_pad == 0) cached[lc4] = r;
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(mu);
+    cached[dev][kern] = r;
+  }
   return r;
 }
+}  // namespace
+
+uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad) { return resident_blocks(lc4 ? kKernFast16 : kKernFast8, lds_pad); }
 
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                        milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag) {
@@ -75,48 +100,54 @@ hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint
   return hipGetLastError();
 }
 
-bool fast8_takes_pb4() {
-#ifdef MILZMA_LOOP_NO_PB4
-  return false;
-#else
-  return true;
-#endif
-}
-
-size_t slice_ctx_bytes(bool lc4) { return size_t(lc4 ? SliceCtx<16>::kDwords : SliceCtx<8>::kDwords) * sizeof(uint32_t); }
+// one stride for both instantiations (the larger one's): the parked states of a batch are indexed by unit, whatever class it ran in
+size_t slice_ctx_bytes() { return size_t(std::max(SliceCtx<16>::kDwords, SliceCtx<8>::kDwords)) * sizeof(uint32_t); }
 size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap) * sizeof(uint32_t); }
 
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem) {
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow) {
   if (n == 0) return hipSuccess;
   auto* q = static_cast<SliceQueue*>(d_queue);
   auto* ring = reinterpret_cast<uint32_t*>(q + 1);
   if (hipError_t e = hipMemsetAsync(d_flag, 1, sizeof(uint32_t), stream); e != hipSuccess) return e;  // all waves start together: rotate
   // persistent waves: what the chip holds of THIS kernel (it keeps more registers alive than the ordinary one; never more than that one's)
-  static uint32_t cached[2] = {0, 0};
-  uint32_t resident = fast_resident_blocks(lc4, lds_pad);
-  if (lds_pad == 0 && cached[lc4]) {
-    resident = cached[lc4];
-  } else {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    const hipError_t e = lc4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<16>, int(kWave), lds_pad)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<8>, int(kWave), lds_pad);
-    if (e == hipSuccess && per_cu > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      resident = std::min(resident, uint32_t(per_cu) * uint32_t(prop.multiProcessorCount));
-    else
-      (void)hipGetLastError();
-    if (lds_pad == 0) cached[lc4] = resident;
-  }
+  const uint32_t resident = std::min(fast_resident_blocks(lc4, lds_pad), resident_blocks(lc4 ? kKernSliced16 : kKernSliced8, lds_pad));
   const uint32_t waves = std::min(n, resident);
   hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
-                     d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem));
+                     d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem), grow ? 1u : 0u,
+                     uint32_t(slice_ctx_bytes() / sizeof(uint32_t)));
   if (lc4)
     hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<16>, dim3(waves), dim3(kWave), lds_pad, stream, q);
   else
     hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<8>, dim3(waves), dim3(kWave), lds_pad, stream, q);
+  return hipGetLastError();
+}
+
+// d_dst[dst_off[i], +len[i]) = d_src[src_off[i], +len[i]): one block per range, 16 bytes per lane and step where both ends are
+// 16-byte aligned (the library's own slices are 256-byte aligned), bytes otherwise.  HBM-bound: what carries the output of
+// parked units into their larger slices (milzma_move_units).
+__global__ __launch_bounds__(256) void move_units_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint64_t* __restrict__ offs,
+                                                         uint32_t n) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint64_t so = offs[i], dof = offs[n + i], len = offs[2 * size_t(n) + i];
+  const uint8_t* s = src + so;
+  uint8_t* d = dst + dof;
+  uint64_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+    const uint64_t vecs = len / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    for (uint64_t k = threadIdx.x; k < vecs; k += blockDim.x) d4[k] = s4[k];
+    done = vecs * 16;
+  }
+  for (uint64_t k = done + threadIdx.x; k < len; k += blockDim.x) d[k] = s[k];
+}
+
+hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(move_units_kernel, dim3(n), dim3(256), 0, stream, d_src, d_dst, d_offs, n);
   return hipGetLastError();
 }
 

@@ -29,11 +29,8 @@ def _hdr(comp):
 
 @pytest.fixture(scope="module")
 def loops():
-    import gen_fast_loop as G
-    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "lc4": asmprog.AsmLoop(lp0=False, pb4=True, lc4=True)}
-    # (a generator run without the PB4 variant -- MILZMA_GEN_NOPB4, the build for five waves per SIMD -- sends pb 3 / 4 to the LC4 loop,
-    #  as that build's kernel does)
-    m["pb4"] = m["lc4"] if getattr(G, "NOPB4", False) else asmprog.AsmLoop(lp0=False, pb4=True)
+    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "lc4": asmprog.AsmLoop(lp0=False, pb4=True, lc4=True),
+         "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}
     yield m
     for a in set(m.values()):
         a.close()

@@ -80,6 +80,7 @@ class Program:
         self.labels = {}
         self.text = []    # instruction text per index
         self.region = []  # innermost preceding label per instruction
+        self.tag = []     # (section, role) per instruction, from the generator (profile.py --sections)
         cur = "entry"
         for ln in lines:
             s = ln.strip()
@@ -92,6 +93,7 @@ class Program:
                 continue
             self.text.append(s)
             self.region.append(cur)
+            self.tag.append((getattr(ln, "sec", ""), getattr(ln, "role", "")))
         self.encoded = [self._encode(i, t) for i, t in enumerate(self.text)]
 
     def _reg(self, tok):
@@ -302,8 +304,8 @@ class AsmLoop:
             self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
         for i in range(4):
             self.vset(self.ps0 + i, 0x400)
-        if self.mvbase:      # matched rows that live in VGPRs: LC4's rows 12..15, row 7 of the 8-row variants built for five waves per SIMD
-            for i in range(16 if self.lit_regs == 32 else 4 * (8 - getattr(G, "VROW8", 8))):
+        if self.mvbase:      # matched rows that live in VGPRs: LC4's rows 12..15
+            for i in range(16):
                 self.vset(self.mvbase + i, 0x04000400)
         lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
         self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)

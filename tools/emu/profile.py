@@ -19,6 +19,60 @@ import asmprog  # noqa: E402
 from lzma_rs_amd import workloads as W  # noqa: E402
 
 
+ROLES = ("core", "update", "normtest", "normstub", "book")
+CLASSES = ("salu", "valu", "branch", "misc", "lds", "vmem")
+
+
+def sections_table(emu, n, a, executed):
+    """Where the executed instructions sit: loop section (rows) x role in a decision (columns) and x instruction class.
+    core = the instructions of a decision itself (bound, compare, select, symbol), update = probability updates, normtest = the
+    `range < 2^24` compare + branch after every decision, normstub = the normalisation proper (one per input byte), book = the rest
+    (state, indices, guards, row swaps, stores, copies, jumps)."""
+    import json
+    c, tk = emu.counts()
+    tab = {}
+    for i, text in enumerate(emu.prog.text):
+        sec, role = emu.prog.tag[i]
+        d = tab.setdefault(sec or "?", {})
+        k = asmprog.classify(text)
+        d[role] = d.get(role, 0) + int(c[i])
+        d["_" + k] = d.get("_" + k, 0) + int(c[i])
+        d["_taken"] = d.get("_taken", 0) + int(tk[i])
+    rows = sorted(tab.items(), key=lambda kv: -sum(v for k, v in kv[1].items() if not k.startswith("_")))
+    hdr = "%-18s %8s | " % ("section", "instr/B") + " ".join("%8s" % r for r in ROLES) + " | " + " ".join("%7s" % k for k in CLASSES) + " %7s" % "taken"
+    print(hdr)
+    out_rows = {}
+    tot = {}
+    for sec, d in rows:
+        total = sum(d.get(r, 0) for r in ROLES)
+        if not total:
+            continue
+        print("%-18s %8.3f | " % (sec, total / n) + " ".join("%8.3f" % (d.get(r, 0) / n) for r in ROLES) + " | " +
+              " ".join("%7.3f" % (d.get("_" + k, 0) / n) for k in CLASSES) + " %7.3f" % (d.get("_taken", 0) / n))
+        out_rows[sec] = {"total": round(total / n, 4), "by_role": {r: round(d.get(r, 0) / n, 4) for r in ROLES},
+                         "by_class": {k: round(d.get("_" + k, 0) / n, 4) for k in CLASSES}, "taken_branches": round(d.get("_taken", 0) / n, 4)}
+        for k, v in d.items():
+            tot[k] = tot.get(k, 0) + v
+    total = sum(tot.get(r, 0) for r in ROLES)
+    print("%-18s %8.3f | " % ("all", total / n) + " ".join("%8.3f" % (tot.get(r, 0) / n) for r in ROLES) + " | " +
+          " ".join("%7.3f" % (tot.get("_" + k, 0) / n) for k in CLASSES) + " %7.3f" % (tot.get("_taken", 0) / n))
+    import bench
+    with open(a.sections, "w") as f:
+        json.dump({"kernel_source_sha256": bench.kernel_source_hash(),
+                   "workload": "%s, %d streams of %d B (indices %d..%d of bench.py's recipe), dict %d"
+                               % (a.kind, a.streams, a.size, a.index, a.index + a.streams - 1, a.dict),
+                   "how": "tools/emu/profile.py --sections: the generated symbol loop executed instruction by instruction on the CPU (bit-exact "
+                          "output); every executed instruction attributed to the loop section and the role the generator emitted it for "
+                          "(tools/gen_fast_loop.py: Gen.sec / @role); instructions per output byte",
+                   "roles": {"core": "the decision itself (bound, compare, select, symbol bit)", "update": "probability updates",
+                             "normtest": "range < 2^24 compare + branch after every decision", "normstub": "normalisation proper (one per input byte)",
+                             "book": "state, indices, guards, row swaps, stores, copies, jumps"},
+                   "sections": out_rows,
+                   "all": {"total": round(total / n, 4), "by_role": {r: round(tot.get(r, 0) / n, 4) for r in ROLES},
+                           "by_class": {k: round(tot.get("_" + k, 0) / n, 4) for k in CLASSES}}}, f, indent=1)
+        f.write("\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1 << 20)
@@ -27,6 +81,7 @@ def main():
     ap.add_argument("--regions", type=int, default=0)
     ap.add_argument("--index", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="average over this many streams (indices index .. index + streams - 1)")
+    ap.add_argument("--sections", default="", help="write the per-section / per-role table (instructions per output byte) to this JSON file and print it")
     ap.add_argument("--json", default="", help="also write the mix to this file (bench.py reads profiles/r03_instruction_mix_<config>.json)")
     a = ap.parse_args()
     emu = None
@@ -63,6 +118,8 @@ def main():
                        "per_output_byte": {k: round(mix.get(k, 0) / n, 4) for k in ("salu", "valu", "branch", "misc", "lds", "vmem", "total", "taken")},
                        "executed_instructions": executed, "compressed_bytes": comp_bytes}, f, indent=1)
             f.write("\n")
+    if a.sections:
+        sections_table(emu, n, a, executed)
     if a.regions:
         c, tk = emu.counts()
         reg = {}

@@ -115,22 +115,16 @@ EOFWRAP = OFFBIAS and os.environ.get("MILZMA_GEN_EOFWRAP", "1") == "1"
 # PINV = first VGPR of a fixed block for the model registers the compiler otherwise places (OPS_INOUT_V: 35 registers); 0 = its choice.
 # (The same loop ran 33 % slower inside the time-sliced kernel than inside the ordinary one at 4 waves per SIMD, identical text,
 #  different register numbers: with the block pinned both kernels run the loop on the same registers.)
-PINV = int(os.environ.get("MILZMA_GEN_PINV", "0"))
+# Round 4, alternating A/B on the bench batch (profiles/r04_kernel_ab.txt): PINV=20 -0.4 %, with LITSPLIT -0.7 %: both are the default now.
+PINV = int(os.environ.get("MILZMA_GEN_PINV", "20"))
 # LITSPLIT: the two dwords of a plain literal row r at v[64 + r] and v[64 + rows + r] instead of v[64 + 2r], v[65 + 2r]: the gpr index
 # of a row is the row itself, not twice it -- two scalar shifts less per row swap (0.14 per byte on text, 1.75 on random data).
-# Prepared in round 3 (bit-exact on the emulator), not timed yet: default off.
-LITSPLIT = os.environ.get("MILZMA_GEN_LITSPLIT", "0") == "1"
+# Round 4: timed (see PINV above), default on.
+LITSPLIT = os.environ.get("MILZMA_GEN_LITSPLIT", "1") == "1"
 # VBASE: first register of the loop's fixed VGPR block (literal table, pos_slot trees, temporaries and per-lane constants: 56 registers,
-# 72 for lc + lp = 4).  64 (the default) puts the block's top at v119: the kernel cannot have fewer than 120 VGPRs whatever the compiler
-# does.  40, with the model registers pinned below it (PINV=1: v1..v35), keeps everything the loop names below v96 -- what a fifth wave per
-# SIMD needs (kernel built with -DMILZMA_WAVES_PER_SIMD=5; the time-sliced launch then runs 5120 persistent waves).  Prepared in round 3.
+# 72 for lc + lp = 4).  64 (the default) puts the block's top at v119.  (Round 3 also had VROW8 / NOPB4 for a five-waves-per-SIMD build of
+# the 8-row variants: +2.9 % for >= 5120 streams, nothing for 4096 -- removed in round 4, profiles/r03_kernel_ab.txt.)
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
-# The rest of what a fifth wave per SIMD needs (20 waves x 8 KiB are exactly a CU's LDS, and the hardware did not place them):
-# VROW8 = 7: in the 8-row variants (lc + lp <= 3) the matched sub-tables of literal row 7 live in 4 VGPRs, rows 0..6 in 7 KiB of LDS
-# (the mechanism the LC4 variant uses for its rows 12..15); NOPB4 = 1: no PB4 variant and none of its 8 model registers -- streams with
-# pb 3 / 4 go to the LC4 instantiation, which handles any pb.  88 registers named by the loop, below v96.
-VROW8 = int(os.environ.get("MILZMA_GEN_VROW8", "8"))
-NOPB4 = os.environ.get("MILZMA_GEN_NOPB4", "0") == "1"
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
@@ -176,10 +170,7 @@ def set_layout(lc4):
     CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
     # LC4: the matched-literal sub-tables of rows 12..15 live in 16 VGPRs (fixed operands, s_set_gpr_idx indexed), rows 0..11 in
     # LDS: 12 KiB per wave instead of 16 -> 13 blocks per CU fit, and the 151 VGPRs allow 12 (3 per SIMD); with 16 KiB it was 9
-    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if (lc4 or VROW8 < 8) else None
-    if MVBASE and not lc4 and PINV and "OPS_INOUT_V" in globals():   # the 8-row variants' VGPR rows: behind the pinned model registers
-        MVBASE = PINV + len(OPS_INOUT_V) - (len(PB4_ONLY_V) if NOPB4 else 0)
-        assert MVBASE + 4 * (8 - VROW8) <= VBASE
+    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if lc4 else None
 
 
 set_layout(False)
@@ -215,11 +206,34 @@ def R(name):
     return "%%[%s]" % name
 
 
+def role(name):
+    """decorator: the instructions a Gen method emits play this role in a decision (profiling only)"""
+    def deco(f):
+        def wrapped(self, *a, **kw):
+            with self.at(role=name):
+                return f(self, *a, **kw)
+        wrapped.__name__, wrapped.__doc__ = f.__name__, f.__doc__
+        return wrapped
+    return deco
+
+
+class Line(str):
+    """an emitted instruction that remembers which loop section / role it belongs to (tools/emu/profile.py --sections)"""
+    sec = ""
+    role = ""
+
+
+class QE(tuple):
+    """a queued (deferred) instruction: (text, reads_sym, reads_vcc); `tag` = (section, role) of where it was queued (not part of
+    the queue's identity: two paths that queue the same update arrive with the same queue)"""
+    tag = ("", "")
+
+
 class Gen:
     def __init__(self, lp0, pb4=False, lc4=False):
         set_layout(lc4)  # (lc4: lc + lp = 4 -- 16 literal rows; same code, other register numbers and 16 KiB of LDS rows)
         self.lc4 = lc4
-        self.vrow0 = VROW0 if lc4 else (VROW8 if VROW8 < 8 else None)   # first matched row that lives in VGPRs (None: all in LDS)
+        self.vrow0 = VROW0 if lc4 else None   # first matched row that lives in VGPRs (None: all in LDS)
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
         # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
@@ -233,6 +247,7 @@ class Gen:
         self.q = []
         self.reach = True
         self.lstate = {}
+        self.sec, self.role = "prologue", "book"   # attribution of what is emitted (profiling only)
 
     ANY_STATE = ("Xeof", "Xmatch_dist_dict", "Xmatch_dist_out")   # decoding ends there with an error: the model no longer matters
 
@@ -268,7 +283,9 @@ class Gen:
                 raise AssertionError("sym is overwritten while a deferred update still reads it: " + out)
             if ops[1] == "vcc" and op.startswith("v_") and any(x[2] for x in self.q):
                 raise AssertionError("vcc is overwritten while a deferred update still reads it: " + out)
-        self.cur.append("  " + out)
+        line = Line("  " + out)
+        line.sec, line.role = kw.get("_tag") or (self.sec, self.role)
+        self.cur.append(line)
         if op in ("s_branch", "s_setpc_b64"):
             self.reach = False
 
@@ -318,28 +335,51 @@ class Gen:
         out = fmt
         for n in set(re.findall(r"\{(\w+)\}", fmt)):
             out = out.replace("{%s}" % n, kw[n] if n in kw else R(n))
-        self.q.append((out, reads_sym, reads_vcc))
+        q = QE((out, reads_sym, reads_vcc))
+        q.tag = (self.sec, "update")
+        self.q.append(q)
 
     def shadow(self, n):
         """up to n queued instructions, here"""
         k = 0
         while self.q and k < n:
-            self.e(self.q.pop(0)[0], _queued=True)
+            q = self.q.pop(0)
+            self.e(q[0], _queued=True, _tag=getattr(q, "tag", None))
             k += 1
         return k
 
     def flush(self):
         while self.q:
-            self.e(self.q.pop(0)[0], _queued=True)
+            q = self.q.pop(0)
+            self.e(q[0], _queued=True, _tag=getattr(q, "tag", None))
 
     def flush_reads(self, sym=False, vcc=False):
         """everything up to the last queued instruction that reads sym / vcc"""
         last = max([i for i, x in enumerate(self.q) if (sym and x[1]) or (vcc and x[2])], default=-1)
         for _ in range(last + 1):
-            self.e(self.q.pop(0)[0], _queued=True)
+            q = self.q.pop(0)
+            self.e(q[0], _queued=True, _tag=getattr(q, "tag", None))
 
     def in_cold(self):
         return Gen._Into(self, self.cold)
+
+    class _At:
+        """with g.at(sec=..., role=...): what is emitted inside is attributed to that section / role (profiling only)"""
+        def __init__(self, g, sec, role):
+            self.g, self.new = g, (sec, role)
+
+        def __enter__(self):
+            self.saved = (self.g.sec, self.g.role)
+            if self.new[0] is not None:
+                self.g.sec = self.new[0]
+            if self.new[1] is not None:
+                self.g.role = self.new[1]
+
+        def __exit__(self, *a):
+            self.g.sec, self.g.role = self.saved
+
+    def at(self, sec=None, role=None):
+        return Gen._At(self, sec, role)
 
     # ---- range coder ------------------------------------------------------------------------------
     def norm(self, to=None, kind="single"):
@@ -348,19 +388,21 @@ class Gen:
         k = self.new("N")
         if to is not None and self.q and self.lstate.get(to, ()) == ():
             self.flush()          # (the stub branches to `to` as well: both must arrive with what the label expects)
-        if kind in NORM_S:
-            self.e("s_cmp_lt_u32 {range}, 0x1000000")
-            self.e("s_cbranch_scc1 " + self.L(k))
-        else:
-            self.e("v_cmp_lt_u32 vcc, {range}, {VKTOP}")     # all lanes agree
-            self.e("s_cbranch_vccnz " + self.L(k))
+        with self.at(role="normtest"):
+            if kind in NORM_S:
+                self.e("s_cmp_lt_u32 {range}, 0x1000000")
+                self.e("s_cbranch_scc1 " + self.L(k))
+            else:
+                self.e("v_cmp_lt_u32 vcc, {range}, {VKTOP}")     # all lanes agree
+                self.e("s_cbranch_vccnz " + self.L(k))
         if to is None:
             ret = self.new("R")
             self.lab(ret)
         else:
             ret = to
-            self.e("s_branch " + self.L(to))
-        with Gen._Into(self, self.stubs):
+            with self.at(role="book"):
+                self.e("s_branch " + self.L(to))
+        with Gen._Into(self, self.stubs), self.at(role="normstub"):
             self.lab(k)
             if not EOFWRAP:
                 self.e("s_cmp_eq_u32 {off}, {lim}")
@@ -387,6 +429,7 @@ class Gen:
         for _ in range(PAD_B):
             self.e("s_cbranch_execz " + self.L("finish"))
 
+    @role("core")
     def core(self, T, ln, half=None, cmp_lane=None, formb=False):
         """decode_bit (rangecoder.rs:92-120) on the probability in lane `ln` of T, up to the point where
         SCC = (bit == 0) and range / code are updated.  half: None = T holds one probability per lane;
@@ -434,6 +477,7 @@ class Gen:
         self.e("s_cselect_b32 {range}, {sb}, {sr1}")
         self.e("s_cselect_b32 {code}, {code}, {sc1}")
 
+    @role("update")
     def _apply(self, T, half):
         self.e("v_ashrrev_i32 {vt}, 5, {vt}")            # (K - p) >> 5, arithmetic
         if half == 1:
@@ -443,6 +487,7 @@ class Gen:
 
     # p += (K - p) >> 5 with K = 2048 for a 0 bit and 31 for a 1 bit (the arithmetic shift makes the second
     # -(p >> 5)); for an unpacked probability this is (31 * p + K) >> 5: one v_mad and one shift.
+    @role("update")
     def post_known(self, T, bit0, half=None, defer=True):
         """probability update when the bit value is known from the branch taken"""
         if half is None:
@@ -459,10 +504,12 @@ class Gen:
         self.e("v_sub_u32 {vt}, %s, {vx}" % ("0x800" if bit0 else "31"))
         self._apply(T, half)
 
+    @role("update")
     def pre_sym(self):
         """scalar part of the update of a tree decision; call while SCC = (bit == 0)"""
         self.e("s_cselect_b32 {sk}, 0x800, 31")
 
+    @role("update")
     def post_sym(self, T, half=None, defer=True):
         """probability update of a tree decision (the symbol's new low bit is 1 if the bit was 0)"""
         if half is None:
@@ -478,6 +525,7 @@ class Gen:
         self.e("v_sub_u32 {vt}, {sk}, {vx}")
         self._apply(T, half)
 
+    @role("core")
     def bit(self, T, ln, half=None, first=False, cmp_lane=None, defer=True):
         """one tree decision: sym = 2 * sym + (bit == 0), then normalise.  first: sym was 1 (not
         materialised), ln is the constant lane of the root."""
@@ -488,6 +536,7 @@ class Gen:
         self.post_sym(T, half, defer=defer)
         self.norm()
 
+    @role("core")
     def bit_nu(self, T, ln, first=False):
         """one decision of a tree whose probabilities are updated after the walk (tree_update): 5 scalar +
         4 vector instructions and a wait state"""
@@ -529,6 +578,7 @@ class Gen:
             first = first_lane is not None and i == 0
             self.bit_nu(T, first_lane if first else R("sym"), first=first)
 
+    @role("update")
     def tree_update(self, T, final_level, min_level=None, defer=False):
         """The probability updates of a walked tree, all at once: the final symbol (at heap level
         `final_level`, inverted-bit path) names the visited node of every level (its prefixes) and the bit
@@ -562,6 +612,7 @@ class Gen:
             e("s_and_b64 vcc, vcc, " + MPAIR)
         e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
 
+    @role("core")
     def decide(self, T, ln, taken, cmp_lane=None, defer=True):
         """a decision that ends in a branch: falls through for a 0 bit, jumps to `taken` for a 1 bit.
         The code at `taken` must start with self.taken(T)."""
@@ -595,6 +646,7 @@ class Gen:
         self.post_known(T, False, defer=defer)
         self.norm(to)
 
+    @role("core")
     def direct_bit(self, acc, test=True):
         """RangeDecoder::get_bit (rangecoder.rs:71-82): acc = 2 * acc + (bit == 0).  test=False: the caller knows where the
         normalisations fall (DIRECT8)."""
@@ -605,6 +657,7 @@ class Gen:
         if test:
             self.norm(kind="direct")
 
+    @role("normstub")
     def direct_norm(self, mark=None):
         """RangeDecoder::normalize (rangecoder.rs:59-69), unconditional and inline: range < 2^24 is known here"""
         e, L = self.e, self.L
@@ -1054,20 +1107,23 @@ class Gen:
     def posslot_writeback(self):
         """the walked pos_slot tree (VPS, its update complete) back to the register of its len_state (t5 = len_state + 2)"""
         self.flush()
-        self.e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
-        self.e("v_mov_b32 " + PS0M2 + ", {VPS}")
-        self.e("s_set_gpr_idx_off")
+        with self.at(sec="pos_slot", role="book"):
+            self.e("s_set_gpr_idx_on {t5}, gpr_idx(DST)")
+            self.e("v_mov_b32 " + PS0M2 + ", {VPS}")
+            self.e("s_set_gpr_idx_off")
 
     def distance_tables(self):
         """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
         for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
         e, lab, L = self.e, self.lab, self.L
+        self.sec = "pos_slot"
         e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2  (gfx9 has no v_movrel*: s_set_gpr_idx)
         e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
         e("v_mov_b32 {VPS}, " + PS0M2)
         e("s_set_gpr_idx_off")
         self.tree_walk(V["VPS"], 6, first_lane="1")
         self.tree_update(V["VPS"], 6, defer=True)            # (queued: emitted in the shadows of the align walk; the tree goes
+        self.sec = "dist dispatch"
         e("v_readlane_b32 {t2}, {tbl_a}, {sym}")             #  back to its register once it is complete: posslot_writeback)
         if DIRECT8:
             # entry = offset + ((n + clz) & 7) * chain size - ((n + clz) >> 3) * normalisation size, for every lane
@@ -1092,6 +1148,7 @@ class Gen:
         for name in targets:   # the computed jump's targets arrive with what is queued here
             self.lstate[name] = self._st()
         e("s_setpc_b64 " + JPAIR)
+        self.sec = "direct bits"
         if DIRECT8:
             for v in range(8):
                 lab("dchain%d" % v)
@@ -1116,6 +1173,7 @@ class Gen:
             lab("direct_chain")
             for _ in range(26):
                 self.direct_bit(R("t4"))
+        self.sec = "align"
         lab("direct_done")
         self.tree_walk(R("m_align"), 4, first_lane="1")
         self.posslot_writeback()
@@ -1125,6 +1183,7 @@ class Gen:
         e("s_brev_b32 {t3}, {t3}")                           # a'
         e("s_add_u32 {t4}, {t4}, {t3}")
         e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
+        self.sec = "dist slots < 14"
         with self.in_cold():                                 # falls through into `copy`
             lab("dist_small")
             self.posslot_writeback()
@@ -1242,8 +1301,10 @@ class Gen:
         e("s_cbranch_scc1 " + L("Oentry_fix"))
 
         # ================= after a literal =================
+        self.sec = "is_match"
         self.symbol_top("L")
         # ---- plain literal (lzma.rs:526-561)
+        self.sec = "literal plain"
         self.literal_row("L")
         if STATE_TBL:
             e("v_readlane_b32 {state}, {VSTT}, {state}")     # state after a literal (lzma.rs:472-478)
@@ -1263,15 +1324,18 @@ class Gen:
         # Section order: a new match falls through its distance tail into `copy`, and `copy` into the top after a match, so that
         # the only taken branches of a match are the computed jump into the direct bits and the loop's back edge.
         # ================= match (lzma.rs:480-523) =================
+        self.sec = "is_match"
         if self.pb4:
             lab("match2")                                     # (the update of is_match was done by the register's own stub)
         else:
             lab("match")
             self.taken(R("m_ismatch"))
+        self.sec = "is_rep"
         self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
         e("s_mov_b32 {rep3}, {rep2}")
         e("s_mov_b32 {rep2}, {rep1}")
         e("s_mov_b32 {rep1}, {rep0}")
+        self.sec = "length"
         self.len_decode(0, "len0_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 7, 10")
@@ -1279,18 +1343,22 @@ class Gen:
         self.distance_tables()
 
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
+        self.sec = "copy"
         lab("copy")                                          # mlen = bytes to copy, distance = rep0 + 1
         self.copy_guard1()
 
         # ================= after a match =================
+        self.sec = "is_match"
         self.symbol_top("M")
+        self.sec = "literal matched"
         # ---- matched literal: probs[((1 + match_bit) << 8) + sym] (lzma.rs:541-555).  The row's two
         #      matched sub-tables are in LDS, dword k of a lane = nodes 64k..64k+63, low half for
         #      match_bit 0 and high half for match_bit 1.
         e("s_add_u32 {t6}, {pend_n}, -1")                # complete the pending match, unless (rare) there is none
         e("s_cmpk_ge_u32 {t6}, 0x%x" % (PEND_UNKNOWN - 1))  # (pend_n == 0, entering from C++) or prev / mb are unknown
         e("s_cbranch_scc1 " + L("OpendM_special"))
-        self.finish_pending(have_t6=True, prof="m")
+        with self.at(sec="copy"):
+            self.finish_pending(have_t6=True, prof="m")
         lab("lit_pM")
         self.literal_row("M")
         if STATE_TBL:
@@ -1378,6 +1446,7 @@ class Gen:
             self.prev_fetch("topL")
 
         # ---- rep matches (lzma.rs:483-509)
+        self.sec = "is_rep"
         lab("rep_match")
         self.taken(R("m_rep"))
         e("s_add_u32 {ln}, {state}, 12")
@@ -1423,12 +1492,14 @@ class Gen:
         e("s_mov_b32 {rep1}, {rep0}")
         e("s_mov_b32 {rep0}, {t0}")
         lab("rep_len")
+        self.sec = "length"
         self.len_decode(1, "len1_done")
         e("s_cmpk_lt_u32 {state}, 7")
         e("s_cselect_b32 {state}, 8, 11")
         e("s_branch " + L("copy"))
 
         # ================= out-of-line helpers =================
+        self.sec = "copy"
         with self.in_cold():
             lab("Operiodic")                                  # source index = lane % dist (exact: lane < 64)
             e("s_add_u32 {t0}, {rep0}, 1")
@@ -1475,6 +1546,7 @@ class Gen:
             e("s_mov_b32 {pend_n}, 0")
             e("s_branch " + L("cp_a"))
 
+            self.sec = "refill"
             lab("refill")                                     # subroutine: the window's 64 bytes are used up
             if EOFWRAP:
                 e("s_add_u32 {n0}, {lim}, 1")                 # lim is 0 (nothing beyond this window: the reader is at EOF now) or -1
@@ -1535,6 +1607,7 @@ class Gen:
                 self.set_guards(R("n0"))
                 e("s_setpc_b64 " + RET)
 
+            self.sec = "literal matched"
             lab("Omb_fetch")                                  # lzb.last_n(rep0 + 1)
             e("s_sub_u32 {t1}, {len}, {t0}")
             e("v_mov_b32 {VT0}, {t1}")
@@ -1543,6 +1616,7 @@ class Gen:
             e("v_readfirstlane_b32 {mb}, {VT0}")
             e("s_branch " + L("lm_a"))
 
+            self.sec = "exit"
             lab("Xlimit_undo")
             e("s_add_u32 {len}, {len}, -1")
             self.exit_with("LIMIT")
@@ -1580,8 +1654,6 @@ def main():
     texts, clobbers, fixeds = {}, {}, {}
     for name, lp0, pb4, lc4 in (("LP0", True, False, False), ("GEN", False, False, False), ("PB4", False, True, False),
                                 ("LC4", False, True, True)):
-        if NOPB4 and name == "PB4":
-            continue
         g = Gen(lp0, pb4, lc4)
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
@@ -1591,7 +1663,7 @@ def main():
         clobbers[name] = list(CLOBBER_V)
         fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (VBASE + i, i) for i in range(LIT_REGS)] +
                         ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)] +
-                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16 if lc4 else 4 * (8 - VROW8))] if MVBASE else []))
+                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16)] if MVBASE else []))
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
@@ -1601,10 +1673,6 @@ def main():
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
     out.append("#define MILZMA_LOOP_PEND_UNKNOWN 0x%xu" % PEND_UNKNOWN)
-    if VROW8 != 8:
-        out.append("#define MILZMA_LOOP_VROW8 %d   // 8-row variants: first matched-literal row that lives in VGPRs (default 8: none)" % VROW8)
-    if NOPB4:
-        out.append("#define MILZMA_LOOP_NO_PB4 1   // no PB4 variant: pb 3 / 4 belongs to the LC4 instantiation")
     out.append("#define MILZMA_LOOP_EXIT_RESEEK 0x100u   /* or-ed into the exit code: reload the input windows before reading on */")
     for name, lines in texts.items():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
@@ -1614,7 +1682,7 @@ def main():
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
     assert clobbers["LP0"] == clobbers["GEN"] and fixeds["LP0"] == fixeds["GEN"]
-    assert NOPB4 or (clobbers["LP0"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["PB4"])
+    assert clobbers["LP0"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["PB4"]
 
     def common(vnames):
         return ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
@@ -1622,8 +1690,7 @@ def main():
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
     for sfx, name in (("", "LP0"), ("_LC4", "LC4")):
         out.append("#define MILZMA_FAST_LOOP_OUTPUTS%s \\" % sfx)
-        vnames = [n for n in OPS_INOUT_V if not (NOPB4 and name == "LP0" and n in PB4_ONLY_V)]   # (the LC4 variant handles pb 3 / 4 in any case)
-        out.append("  " + ", \\\n  ".join(common(vnames) + fixeds[name]))
+        out.append("  " + ", \\\n  ".join(common(OPS_INOUT_V) + fixeds[name]))
         out.append("#define MILZMA_FAST_LOOP_CLOBBERS%s \\" % sfx)
         out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + clobbers[name]) + ', "vcc", "scc", "memory"')
     out.append("#define MILZMA_FAST_LOOP_INPUTS \\")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc passes of one bench workload into profiles/r03_pmc_<config>.json (what bench.py's
+"""Turns the rocprofv3 --pmc passes of one bench workload into profiles/r04_pmc_<config>.json (what bench.py's
 roofline.traffic reads, keyed by the kernel source hash).
 
     python tools/make_pmc_profile.py <config> <dir with pass_*/**/*counter_collection.csv> <out.json>
@@ -54,14 +54,23 @@ def main():
                                    "once; reads = one 128-B line of the stream's own LZ77 window per match from beyond the XCD's "
                                    "4 MiB L2 plus the compressed input: byte-granular dictionary reads, ~3 %% of the HBM roofline"
                                    % (cfg["distinct"], cfg["streams"])}
-    for k in ("SQ_INSTS_SALU", "SQ_INSTS_VALU"):
+    for k in ("SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_BRANCH"):
         if k in counters:
             derived[k.lower() + "_per_output_byte"] = counters[k] / out_bytes
+    # where a wave's cycles go (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, all in quad-cycles):
+    # WAIT_ANY = parked in s_waitcnt, WAIT_INST_ANY = an instruction is ready but cannot issue (dependency / pipe / arbitration),
+    # ACTIVE_INST_* = issuing an instruction of that kind
+    if "SQ_WAVE_CYCLES" in counters:
+        wc = counters["SQ_WAVE_CYCLES"]
+        derived["wave_cycle_shares"] = {k[3:].lower(): round(counters[k] / wc, 4) for k in
+                                        ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_SCA",
+                                         "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_MISC")
+                                        if k in counters}
     with open(out, "w") as f:
         json.dump({"kernel_source_sha256": bench.kernel_source_hash(), "config": config,
                    "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py --config %s "
                               "--steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none "
-                              "(experiments/gpu_calls/evidence_r3.sh)" % config,
+                              "(experiments/gpu_calls/r4_evidence.sh)" % config,
                    "dispatches_per_pass": passes, "kernel_ms_under_pmc": round(sum(dur) / max(1, len(dur)), 2),
                    "counters_per_launch": counters, "derived": derived}, f, indent=1)
         f.write("\n")
