@@ -93,6 +93,9 @@ def xz_plain(index, size):
             W.make_plain("text", size - 200_000 - half, W.SEED0 ^ (index + (2 << 24))))
 
 
+KNOWN_SIZE = True   # False: marker-terminated .lzma streams with no size in the header -- what liblzma / `xz --format=lzma` write
+
+
 def _compress_range(job):
     """Worker: compress items [lo, hi) and park them in one /dev/shm file (returning bulk data through the
     pool's pipes would serialise on the parent).  Returns per item (compressed length, [crc32 per unit])."""
@@ -108,7 +111,7 @@ def _compress_range(job):
                 crcs = [zlib.crc32(plain[o:o + (1 << 20)]) for o in range(0, size, 1 << 20)]
             else:
                 plain = W.make_plain(kind, size, W.SEED0 ^ i)
-                comp = W.compress_alone(plain, dict_size=dict_size, lc=lc, lp=lp, pb=pb, known_size=True)
+                comp = W.compress_alone(plain, dict_size=dict_size, lc=lc, lp=lp, pb=pb, known_size=KNOWN_SIZE)
                 crcs = [zlib.crc32(plain)]
             f.write(comp)
             meta.append((len(comp), crcs))
@@ -393,6 +396,115 @@ def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
             "roofline_issue": issue_roofline(name, "text", out_bytes, k_ms, kernel_source_hash())}
 
 
+def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
+    """configs[1] with the headers liblzma itself writes: NO size declared, every stream ends with the end marker (four of
+    the reference's five .lzma fixtures are of this kind).  Nothing tells the decoder how much room a stream needs: every unit gets
+    the slice the whole-file entry points would guess (6 x its payload, at least 64 KiB) and the call is milzma_decode_units_ex with
+    MILZMA_DECODE_GROW -- a unit that outgrows its slice is parked there, not failed.  Timed like the headline (device-resident, K
+    steps, every unit CRC-verified).  Second figure: every guess deliberately HALF of what the stream needs, so that all 4096 units
+    are parked once, given larger slices (their output moved on the device: milzma_move_units) and resumed (MILZMA_DECODE_RESUME):
+    the whole sequence timed, nothing decoded twice."""
+    global KNOWN_SIZE
+    cfg = CONFIGS["lzma64k"]
+    n, size, dict_size, distinct = args.streams or cfg["streams"], args.size or cfg["size"], cfg["dict"], cfg["distinct"]
+    distinct = min(distinct, n)
+    KNOWN_SIZE = False
+    try:
+        units_d, blob_d, _, gen_s = build_batch(distinct, size, "text", dict_size, 0, procs, "lzma")
+    finally:
+        KNOWN_SIZE = True
+    crcs_d = build_batch.crcs
+    reps = (n + distinct - 1) // distinct
+    d_in = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
+    d_in = torch.cat([(d_in.repeat(reps) if reps > 1 else d_in), torch.zeros(512, dtype=torch.uint8)]).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def layout(cap_of):
+        units = (M.Unit * n)()
+        off = comp_total = 0
+        for k in range(n):
+            src = units_d[k % distinct]
+            u = M.Unit()
+            ctypes.memmove(ctypes.byref(u), ctypes.byref(src), ctypes.sizeof(M.Unit))
+            assert u.unpacked_size == M.SIZE_UNKNOWN
+            u.in_off = src.in_off + (k // distinct) * len(blob_d)
+            u.out_off, u.out_cap = off, cap_of(src)
+            off += (u.out_cap + 255) & ~255
+            units[k] = u
+            comp_total += src.in_len
+        return units, off, comp_total
+
+    def verify(units, res, d_out):
+        c32, _ = ctx.crc_units(units, res, d_out.data_ptr(), stream)
+        return sum(1 for k in range(n) if res[k].status != M.ST_OK or res[k].out_len != size or c32[k] != crcs_d[k % distinct])
+
+    # 1. the library's own guess: 6 x payload (what milzma_lzma_decompress_batch starts with)
+    units, out_bytes, comp_total = layout(lambda u: (max(1 << 16, 6 * u.in_len) + 255) & ~255)
+    d_out = torch.empty(out_bytes + 512, dtype=torch.uint8, device=dev)
+    for _ in range(warmup):
+        ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW, stream=stream)
+    torch.cuda.synchronize(dev)
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res, ms, launches = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW, stream=stream)
+        kernel_ms.append(ms)
+    torch.cuda.synchronize(dev)
+    step_s = (time.perf_counter() - t0) / steps
+    d_out.zero_()
+    res, _, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW, stream=stream)
+    parked = sum(1 for r in res if r.status == M.ST_OUT_FULL)
+    bad = verify(units, res, d_out)
+    k_ms = statistics.median(kernel_ms)
+    del d_out
+    torch.cuda.empty_cache()
+
+    # 2. every guess wrong: half the stream's size -> park, grow, move, resume
+    units, out_bytes, _ = layout(lambda u: size // 2)
+    d_out = torch.zeros(out_bytes + 512, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    res, ms1, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW, stream=stream)
+    rounds, parked_total, ms_all = 0, 0, ms1
+    while True:
+        idx = [k for k in range(n) if res[k].status == M.ST_OUT_FULL and res[k].err_a == M.PARKED]
+        if not idx or rounds > 8:
+            break
+        rounds += 1
+        parked_total += len(idx)
+        old = [(units[k].out_off, res[k].out_len) for k in idx]
+        off = 0
+        for k in idx:       # the parked units, packed into a fresh buffer with 2.5 x the room
+            units[k].out_off, units[k].out_cap = off, (units[k].out_cap * 5 // 2 + 255) & ~255
+            off += units[k].out_cap
+        new_out = torch.empty(off + 512, dtype=torch.uint8, device=dev)
+        ctx.move_units(d_out.data_ptr(), [o[0] for o in old], new_out.data_ptr(), [units[k].out_off for k in idx], [o[1] for o in old], stream)
+        d_out = new_out
+        res, ms, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_RESUME, results=res, stream=stream)
+        ms_all += ms
+    torch.cuda.synchronize(dev)
+    wrong_s = time.perf_counter() - t0
+    bad2 = verify(units, res, d_out)
+    del d_out, d_in
+    torch.cuda.empty_cache()
+    out_total = n * size
+    return {"workload": "configs[1] with liblzma's native headers: %d independent %d-byte .lzma streams, NO size in the header, end marker "
+                        "(lc3/lp0/pb2, dict %d, class text); output slices guessed (6 x payload), milzma_decode_units_ex + MILZMA_DECODE_GROW"
+                        % (n, size, dict_size),
+            "value": round(out_total / step_s / 1e9, 4), "unit": "GB/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
+            "bit_exact": bad == 0 and parked == 0, "verified_units": n, "units_parked": parked, "distinct_items": distinct,
+            "generation_s": round(gen_s, 1),
+            "every_guess_wrong": {"what": "all %d slices half the stream's size: every unit parked once, moved into 2.5 x the room on the "
+                                          "device, resumed; wall time of the whole sequence (GROW + move + RESUME), nothing decoded twice"
+                                          % n,
+                                  "value": round(out_total / wrong_s / 1e9, 4), "unit": "GB/s", "seconds": round(wrong_s, 4),
+                                  "kernel_ms_sum": round(ms_all, 3), "rounds": rounds, "units_parked": parked_total, "bit_exact": bad2 == 0},
+            "roofline": {"bound": "hbm", "achieved": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                         "algorithmic_bytes_per_launch": comp_total + out_total, "traffic": None}}
+
+
 def run_inproc(args):
     """--gpus N --inproc: the N GPUs of the node from ONE process through the library's own multi-device entry point
     (milzma_multi_decode_units: one context + one host thread per device inside libmilzma.so, no torch.distributed, no
@@ -514,6 +626,7 @@ def self_launch(n_gpus):
 
 
 def main():
+    global PROPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -527,6 +640,8 @@ def main():
                     help="distinct streams compressed per GPU (0 = all; fewer are tiled over the slots, each "
                          "slot still reads its own copy of the input and writes its own output slice)")
     ap.add_argument("--props", default="3,0,2", help="lc,lp,pb of the generated .lzma streams (default: the BASELINE's 3,0,2)")
+    ap.add_argument("--unknown-size", action="store_true",
+                    help="only configs[1] with marker-terminated headers that declare no size (liblzma's native .lzma): growable output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--pcie", action="store_true",
@@ -544,9 +659,23 @@ def main():
                          "point: a host thread per device) instead of one rank per GPU over torch.distributed")
     ap.add_argument("--dry-run", action="store_true", help="everything up to (not including) the first decode: no GPU needed")
     args = ap.parse_args()
+    PROPS = tuple(int(x) for x in args.props.split(","))
 
     if args.inproc:
         return run_inproc(args)
+    if args.unknown_size:   # one GPU, only the growable-output measurement, printed as a line of its own
+        import torch
+        import lzma_rs_amd as M
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        ctx = M.Context(0)
+        r = run_unknown_size(args, M, torch, dev, ctx, effective_cores(), args.steps, args.warmup)
+        ctx.close()
+        r.update({"metric": "decompressed GB/s, %d x %d B unknown-size .lzma streams per GPU" % (args.streams or 4096, args.size or 1 << 20),
+                  "n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                  "config": {"workload": r.pop("workload")}})
+        print(json.dumps(r))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)
 
@@ -554,8 +683,6 @@ def main():
     import lzma_rs_amd as M
     from lzma_rs_amd import distributed as D
 
-    global PROPS
-    PROPS = tuple(int(x) for x in args.props.split(","))
     cfg = CONFIGS[args.config]
     mode = "xz" if args.config == "xz" else "lzma"
     n = args.streams or cfg["streams"]
@@ -722,12 +849,15 @@ def main():
     if want == "auto":
         default_run = (world == 1 and args.config == "lzma64k" and args.kind == "text" and not args.streams and not args.size
                        and not args.dict and args.props == "3,0,2")
-        want = "dict8m,xz" if default_run else "none"
+        want = "dict8m,xz,unknown_size" if default_run else "none"
     if want != "none":
         del d_in, d_out
         torch.cuda.empty_cache()
         for name in want.split(","):
-            others[name] = run_other_config(name, args, M, torch, dev, ctx, procs, args.other_steps, 1)
+            if name == "unknown_size":
+                others[name] = run_unknown_size(args, M, torch, dev, ctx, procs, args.other_steps, 1)
+            else:
+                others[name] = run_other_config(name, args, M, torch, dev, ctx, procs, args.other_steps, 1)
             bad_total += 0 if others[name]["bit_exact"] else 1
 
     total_out = out_bytes_rank * world

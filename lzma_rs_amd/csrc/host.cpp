@@ -2122,6 +2122,35 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   return MILZMA_OK;
 }
 
+#ifdef MILZMA_TEST_HOOKS
+// Test builds only (tests/san: this file under ASan + UBSan, no GPU): the XZ container walk -- header, blocks, index, footer, every
+// check the reference makes -- with the caller's LZMA2 decoder standing in for the device.  fn returns a MILZMA_ST_* status and,
+// for MILZMA_ST_OK, the payload's output (*out: malloc'd, taken over here) and how many input bytes it consumed.
+typedef int (*milzma_test_lzma2_fn)(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* consumed, void* user);
+extern "C" int milzma_test_xz_walk(const uint8_t* in, size_t in_len, milzma_test_lzma2_fn fn, void* user, milzma_output* out) {
+  try {
+    const PayloadFn decode = [&](const uint8_t* p, size_t n, size_t, Payload* pl) {
+      uint8_t* o = nullptr;
+      size_t on = 0, used = 0;
+      const int st = fn(p, n, &o, &on, &used, user);
+      memset(&pl->res, 0, sizeof pl->res);
+      pl->res.status = uint32_t(st);
+      pl->res.out_len = pl->res.out_flushed = on;
+      pl->res.in_consumed = used;
+      if (o) pl->own.assign(o, o + on);
+      free(o);
+      pl->own.reserve(1);
+      pl->data = pl->own.data();
+      return true;
+    };
+    return xz_walk(nullptr, in, in_len, decode, out);
+  } catch (const std::exception& e) {
+    if (out) out_fail(out, MILZMA_INFRA_ERROR, "%s", e.what());
+    return MILZMA_INFRA_ERROR;
+  }
+}
+#endif
+
 extern "C" int milzma_xz_decompress(milzma_ctx* ctx, const uint8_t* in, size_t in_len, milzma_output* out) {
   const uint8_t* ins[1] = {in};
   const size_t lens[1] = {in_len};

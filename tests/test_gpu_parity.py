@@ -879,3 +879,123 @@ def test_time_sliced_launches_match_ordinary_ones(monkeypatch):
             assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed), i
     finally:
         c.close()
+
+
+# ---- growable output: units parked at the end of their slice and resumed in a larger one (milzma_decode_units_ex) ----------------
+
+def _resume_until_done(ctx, units, d_in, make_out, first_out, max_rounds=40):
+    """GROW, then as long as units are parked: a fresh, larger output buffer, the parked units' bytes moved into their new slices on
+    the device, RESUME.  Returns (results, final output tensor, rounds, parked-ever count)."""
+    import torch
+    n = len(units)
+    d_out = first_out
+    res, _, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW)
+    rounds, ever = 0, 0
+    while True:
+        parked = [i for i in range(n) if res[i].status == M.ST_OUT_FULL and res[i].err_a == M.PARKED]
+        if not parked:
+            return res, d_out, rounds, ever
+        ever += len(parked)
+        rounds += 1
+        assert rounds < max_rounds
+        # everything gets a new place in a new buffer (finished units keep their bytes too: the test compares at the end)
+        old = [(units[i].out_off, units[i].out_cap) for i in range(n)]
+        total = 0
+        for i in range(n):
+            cap = units[i].out_cap
+            if i in set(parked):
+                assert res[i].out_len <= cap, (res[i].out_len, cap)
+                cap = cap * 3 + 512
+            units[i].out_off, units[i].out_cap = total, cap
+            total += (cap + 255) & ~255
+        new_out = make_out(total)
+        lens = [min(res[i].out_len, old[i][1]) for i in range(n)]
+        ctx.move_units(d_out.data_ptr(), [o[0] for o in old], new_out.data_ptr(), [units[i].out_off for i in range(n)], lens)
+        d_out = new_out
+        res, _, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_RESUME, results=res)
+
+
+def test_growable_units_park_and_resume(ctx):
+    """Unit level, device resident: RAW streams of every class (unknown and known sizes, all property classes of the fast kernels) and
+    LZMA2 units (compressed, stored and dictionary-reset chunks) start in slices of a few hundred bytes to a few KiB and are parked /
+    moved / resumed until they end: bytes, status, reader position equal the oracle's; nothing is decoded twice (the sum of the
+    kernels' work is checked through in_consumed never going backwards)."""
+    import torch
+    rng = random.Random(4)
+    comps, refs, kinds = [], [], []
+    for i in range(36):
+        kind = ["text", "zeros", "repeat", "random"][i % 4]
+        lc, lp, pb = [(3, 0, 2), (0, 2, 0), (1, 1, 4), (4, 0, 2), (2, 2, 3), (3, 0, 2)][i % 6]
+        p = W.make_plain(kind, rng.randint(1, 90000), seed=300 + i)
+        c = W.compress_alone(p, dict_size=rng.choice([4096, 1 << 16]), known_size=(i % 3 == 0), lc=lc, lp=lp, pb=pb)
+        if i % 9 == 7:
+            c = c[:len(c) * 2 // 3]                      # truncated: the error must be the oracle's, wherever the unit was parked before
+        comps.append(c)
+        refs.append(orc.lzma_decompress(c))
+        kinds.append(M.KIND_RAW_LZMA)
+    raws = [lzma.compress(W.make_plain("text", 200000, seed=9) + os.urandom(70000) + b"xyz" * 30000, format=lzma.FORMAT_RAW,
+                          filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}]),
+            lzma.compress(os.urandom(150000), format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 12}])]
+    for r in raws:
+        comps.append(r)
+        refs.append(orc.lzma2_decompress(r))
+        kinds.append(M.KIND_LZMA2)
+    n = len(comps)
+    units = (M.Unit * n)()
+    in_off, blobs, total = 0, [], 0
+    for i, c in enumerate(comps):
+        if kinds[i] == M.KIND_RAW_LZMA:
+            u, hl = M.lzma_read_header(c)
+        else:
+            u, hl = M.Unit(), 0
+            u.kind = M.KIND_LZMA2
+        payload = c[hl:]
+        u.in_off, u.in_len = in_off, len(payload)
+        u.out_cap = [300, 1000, 4096, 70000][i % 4]
+        u.out_off = total
+        total += (u.out_cap + 255) & ~255
+        units[i] = u
+        pad = (-len(payload)) % 256
+        blobs.append(payload + bytes(pad))
+        in_off += len(payload) + pad
+    d_in = torch.frombuffer(bytearray(b"".join(blobs) + bytes(512)), dtype=torch.uint8).cuda()
+    make = lambda nbytes: torch.zeros(nbytes + 512, dtype=torch.uint8, device="cuda")
+    res, d_out, rounds, ever = _resume_until_done(ctx, units, d_in, make, make(total))
+    host = d_out.cpu().numpy().tobytes()
+    fast = os.environ.get("MILZMA_KERNEL") != "generic"
+    for i in range(n):
+        ref, r = refs[i], res[i]
+        kind, msg = M.result_message(r, kinds[i])
+        if r.status == M.ST_OUT_FULL:       # only the generic kernel's units may end like this (they cannot be parked)
+            assert not fast and r.err_a == 0, (i, r.status, r.err_a)
+            continue
+        assert (kind, msg) == (ref.kind, ref.msg), (i, msg, ref.msg)
+        got = host[units[i].out_off:units[i].out_off + min(r.out_flushed, units[i].out_cap)]
+        assert got == ref.out, (i, len(got), len(ref.out))
+        if ref.ok:
+            assert r.in_consumed + (13 if kinds[i] == M.KIND_RAW_LZMA else 0) == ref.in_consumed, i
+    if fast:
+        assert ever >= n // 2 and rounds >= 3, (ever, rounds)
+
+
+def test_thousands_of_wrong_guesses_are_resumed_not_redecoded(ctx):
+    """4200 marker-terminated streams whose output is a thousand times their input (zeros / repeats: the whole-file path's first
+    slice, 6 x the payload or 64 KiB, is wrong for every one of them) next to text streams whose guess holds: the batch call parks
+    and resumes them -- bytes and reader position are the oracle's for every file."""
+    plains = [W.make_plain("zeros", 150_000 + 4096 * i, seed=i) for i in range(6)] + \
+             [W.make_plain("repeat", 120_000 + 1000 * i, seed=40 + i) for i in range(6)] + \
+             [W.make_plain("text", 30_000, seed=90), W.make_plain("text", 90_000, seed=91)]
+    comps = [W.compress_alone(p, dict_size=65536, known_size=False) for p in plains]
+    refs = [orc.lzma_decompress(c) for c in comps]
+    many = [comps[i % len(comps)] for i in range(4200)]
+    for i, d in enumerate(ctx.lzma_batch(many)):
+        r = refs[i % len(comps)]
+        assert (d.kind, d.msg, d.in_consumed) == (r.kind, r.msg, r.in_consumed), i
+        assert d.data == r.out, i
+    # a declared size that lies (too small a guess is impossible then: the header is believed up to what the payload can plausibly
+    # expand to) and single-file calls take the same path
+    d = ctx.lzma(comps[0])
+    assert d.ok and d.data == plains[0]
+    raw = lzma.compress(plains[7] * 4, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}])
+    d = ctx.lzma2(raw)
+    assert d.ok and d.data == plains[7] * 4
