@@ -37,5 +37,8 @@ nm = sum(r.err_a & 0xFFFFFFFF for r in res) / n
 wc = sum(r.err_b >> 32 for r in res) / n
 nc = sum(r.err_b & 0xFFFFFFFF for r in res) / n
 print("kernel %.1f ms, %d streams, dict %d" % (ms, n, dict_size))
-print("matched-literal site: %.0f events/stream, %.0f ticks each (s_memtime, 100 MHz), %.1f ms per stream" % (nm, wm / max(nm, 1), wm / 1e5))
-print("copy site:            %.0f events/stream, %.0f ticks each, %.1f ms per stream" % (nc, wc / max(nc, 1), wc / 1e5))
+# s_memtime counts SHADER cycles on gfx950 (~2.4 GHz under this load), not 100 MHz ticks: round 1 read it as 10 ns ticks and
+# overstated these waits 24-fold; profiles/r02_wait_attribution.txt carries that wrong unit in its labels.
+CLOCK_HZ = 2.4e9
+print("matched-literal site: %.0f events/stream, %.0f cycles each (s_memtime: shader cycles), %.2f ms per stream" % (nm, wm / max(nm, 1), wm / CLOCK_HZ * 1e3))
+print("copy site:            %.0f events/stream, %.0f cycles each, %.2f ms per stream" % (nc, wc / max(nc, 1), wc / CLOCK_HZ * 1e3))

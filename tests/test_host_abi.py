@@ -183,3 +183,21 @@ def test_rust_shim_declares_the_header_abi():
         rm = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, flags=re.S)
         r_fields = re.findall(r"pub (\w+):", rm.group(1))
         assert c_fields == r_fields, (name, c_fields, r_fields)
+
+
+def test_asm_loops_sit_in_the_code_object_untouched():
+    """Every instance of the generated symbol loop (LP0 / GEN / PB4 in the <8> kernels, LC4 in the <16> ones; ordinary and time-sliced
+    instantiations: eight in all) is found in the built code object instruction for instruction -- so nothing of the compiler's, in
+    particular none of the scratch_ spill traffic the time-sliced instantiations carry around the loop, sits between a loop's first
+    and last instruction.  The ordinary kernels must stay (nearly) scratch-free altogether; the sliced ones are bounded."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_code_object as C
+    rep, problems = C.check(os.path.join(ROOT, "lzma_rs_amd", "libmilzma.so"))
+    assert not problems, problems
+    assert len(rep["loops"]) == 8
+    for name, m in rep["kernels"].items():
+        if "sliced" in name:
+            assert m["private_segment_fixed_size"] <= 2048, (name, m)
+        else:
+            assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
+        assert m["vgpr_count"] <= (128 if "ILi8E" in name else 168), (name, m)     # 4 / 3 waves per SIMD
