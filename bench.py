@@ -534,6 +534,8 @@ def run_inproc(args):
         cpu_line = cpu_baseline(1 << 20 if mode == "xz" else size, args.kind, dict_size, cores)
     m = M.MultiContext((1 << nd) - 1)
     upi = len(per_dev[0][0]) // distinct
+    if args.scatter:
+        return run_inproc_rooted(args, M, torch, m, per_dev, cfg, mode, n, size, dict_size, nd, distinct, upi, gen_s, cpu_line)
     all_units, device_of, d_ins, d_outs, comp_total = [], [], [], [], 0
     for d, (units_d, blob_d, _) in enumerate(per_dev):
         units, comp = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
@@ -602,6 +604,81 @@ def run_inproc(args):
                          "traffic_note": "per GPU; see the one-process-per-GPU line for the PMC-backed figure",
                          "kernel": "decode kernel(s) of one device's share (slowest device)", "kernel_ms": round(k_ms, 3),
                          "kernel_source_sha256": kernel_source_hash(), "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu_line}
+    print(json.dumps(line))
+    m.close()
+    if bad:
+        raise SystemExit("bench: %d units failed verification" % bad)
+
+
+def run_inproc_rooted(args, M, torch, m, per_dev, cfg, mode, n, size, dict_size, nd, distinct, upi, gen_s, cpu_line):
+    """--gpus N --inproc --scatter: ONE ingest point behind the C ABI (north_star: "input scatter and output gather over xGMI").
+    All N x n streams are resident on device 0 and their output is wanted there: milzma_multi_decode_units_rooted partitions them
+    over the handle's devices, ships every other device its share device to device (hipMemcpyPeer), decodes everywhere at once and
+    brings the outputs back into place.  A step = one such call; `value` counts all of it (copies included: it is what a caller of
+    that entry point gets), the split is in `rooted`.  Every unit CRC-verified on device 0."""
+    per = n * upi
+    all_units, blobs, comp_total, in_off = [], [], 0, 0
+    for d, (units_d, blob_d, _) in enumerate(per_dev):
+        units, comp = tile_units(M, units_d, len(blob_d), n, distinct, upi, size)
+        comp_total += comp
+        reps = (n + distinct - 1) // distinct
+        for u in units:
+            v = M.Unit()
+            ctypes.memmove(ctypes.byref(v), ctypes.byref(u), ctypes.sizeof(M.Unit))
+            v.in_off += in_off
+            v.out_off += d * n * size
+            all_units.append(v)
+        h = torch.frombuffer(bytearray(blob_d), dtype=torch.uint8)
+        blobs.append(h.repeat(reps) if reps > 1 else h)
+        in_off += len(blob_d) * reps
+    arr = (M.Unit * len(all_units))(*all_units)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    d_in = torch.cat(blobs + [torch.zeros(512, dtype=torch.uint8)]).to(dev)
+    d_out = torch.empty(nd * n * size + 512, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        m.decode_units_rooted(0, arr, d_in.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize(dev)
+    splits = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, t = m.decode_units_rooted(0, arr, d_in.data_ptr(), d_out.data_ptr())
+        splits.append(t)
+    torch.cuda.synchronize(dev)
+    step_s = (time.perf_counter() - t0) / args.steps
+    d_out.zero_()
+    torch.cuda.synchronize(dev)     # (the library's streams do not order themselves behind torch's)
+    res, _ = m.decode_units_rooted(0, arr, d_in.data_ptr(), d_out.data_ptr())
+    c = M.Context(0)
+    bad = verified = 0
+    for d in range(nd):
+        sub = (M.Unit * per)(*all_units[d * per:(d + 1) * per])
+        subres = (M.Result * per)(*[res[d * per + i] for i in range(per)])
+        for i in range(per):            # (verify_units addresses a device's units from that device's first slot)
+            sub[i].out_off -= d * n * size
+        b, v = verify_units(M, c, sub, subres, d_out[d * n * size:], 0, per_dev[d][2], n, upi, distinct, size, mode)
+        bad += b
+        verified += v
+    c.close()
+    total_out = n * size * nd
+    med = lambda k: round(statistics.median(x[k] for x in splits), 3)
+    line = {"metric": "decompressed GB/s (whole node), %d x %d B LZMA streams, one ingest point" % (n * nd, size),
+            "value": round(total_out / step_s / 1e9, 4), "unit": "GB/s", "n_gpus": nd, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic", "bit_exact": bad == 0,
+            "config": {"workload": "configs[%d] through ONE ingest point: %d streams of %d B resident on device 0, output gathered there; "
+                                   "milzma_multi_decode_units_rooted over devices %s (device-to-device copies, no collective, no host staging)"
+                                   % (cfg["idx"], n * nd, size, m.devices),
+                       "streams_per_gpu": n, "verified_units": verified, "generation_s": round(gen_s, 1)},
+            "rooted": {"scatter_ms": med(0), "decode_ms": med(1), "gather_ms": med(2),
+                       "note": "slowest device's copy in / decode / copy back + placement on the root, median over the steps (wall clock "
+                               "inside the library); with one device in the handle there is nothing to copy"},
+            "roofline": {"bound": "hbm", "achieved": round((comp_total + total_out) / nd / (med(1) * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round((comp_total + total_out) / nd / (med(1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "one device's decode call (slowest device, incl. descriptor / result copies)",
+                         "kernel_source_sha256": kernel_source_hash(), "algorithmic_bytes_per_launch": (comp_total + total_out) // nd},
             "cpu_baseline": cpu_line}
     print(json.dumps(line))
     m.close()

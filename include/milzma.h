@@ -93,7 +93,9 @@ enum {
                                 grow the slice and decode the unit again from its first byte                              */
   MILZMA_ST_NEED_LCLP = 33,  /* unit needs a literal table for lc+lp = {a} larger than its launch class */
   MILZMA_ST_BAD_UNIT = 34,   /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
-  MILZMA_ST_NEED_GENERIC = 35 /* props outside the fast kernel's specialisation: rerun in the generic one */
+  MILZMA_ST_NEED_GENERIC = 35, /* props outside the fast kernel's specialisation: rerun in the generic one */
+  MILZMA_ST_NEED_RERUN = 36   /* internal to the whole-file calls' streamed launches (their input goes up in two parts): a unit read
+                                 beyond the part that was in place: its output is void, it is decoded again                      */
 };
 
 typedef struct milzma_result {
@@ -305,6 +307,18 @@ int milzma_multi_decode_units_host(milzma_multi *m, const milzma_unit *units, ui
 int milzma_multi_decode_units(milzma_multi *m, const milzma_unit *units, uint32_t n,
                               const uint32_t *device_of, const void *const *d_in, void *const *d_out,
                               milzma_result *results);
+/* One ingest point: the batch's compressed input is resident on ONE device of the handle (index `root` into its device list), the
+ * output is wanted there too (d_in / d_out: device pointers on that device; descriptors and slack rules as for milzma_decode_units).
+ * The units are partitioned over all devices by compressed bytes; the root's share is decoded in place, every other share is packed,
+ * sent to its device with one device-to-device copy (the direct xGMI link where the GPUs have peer access; no host memory, no
+ * collective), decoded there, and its output comes back the same way into the slices the descriptors name.  All devices work
+ * concurrently.  The call works on streams of its own and does not order itself behind work the caller has queued on other
+ * streams: d_in must be complete (and d_out free to be written) when it is made.  results[i]: as from milzma_decode_units.
+ * milzma_multi_last_transfer_ms: the slowest device's copy in, the slowest
+ * decode, and the slowest copy back plus the placement on the root, of the most recent such call (wall-clock ms). */
+int milzma_multi_decode_units_rooted(milzma_multi *m, uint32_t root, const milzma_unit *units, uint32_t n,
+                                     const void *d_in, void *d_out, milzma_result *results);
+void milzma_multi_last_transfer_ms(const milzma_multi *m, float *scatter_ms, float *decode_ms, float *gather_ms);
 /* The whole-file batch entry points over all devices: files are partitioned by size, outs[i] is exactly what the
  * single-device call (and the reference) produces for file i. */
 int milzma_multi_lzma_decompress_batch(milzma_multi *m, uint32_t n, const uint8_t *const *ins,

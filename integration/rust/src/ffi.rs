@@ -267,6 +267,17 @@ extern "C" {
         d_out: *const *mut c_void,
         results: *mut milzma_result,
     ) -> c_int;
+    /// one ingest point: input and output resident on device index `root`; shares travel device to device (xGMI)
+    pub fn milzma_multi_decode_units_rooted(
+        m: *mut milzma_multi,
+        root: u32,
+        units: *const milzma_unit,
+        n: u32,
+        d_in: *const c_void,
+        d_out: *mut c_void,
+        results: *mut milzma_result,
+    ) -> c_int;
+    pub fn milzma_multi_last_transfer_ms(m: *const milzma_multi, scatter_ms: *mut f32, decode_ms: *mut f32, gather_ms: *mut f32);
     pub fn milzma_multi_lzma_decompress_batch(
         m: *mut milzma_multi,
         n: u32,

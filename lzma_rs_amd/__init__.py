@@ -146,6 +146,7 @@ EXPORTS = [
     "milzma_lzma_decompress_batch_async", "milzma_lzma2_decompress_batch_async", "milzma_xz_decompress_batch_async",
     "milzma_batch_wait",
     "milzma_decode_units_ex", "milzma_move_units", "milzma_pool_trim",
+    "milzma_multi_decode_units_rooted", "milzma_multi_last_transfer_ms",
 ]
 
 _lib = None
@@ -217,6 +218,9 @@ def lib():
     L.milzma_multi_decode_units_host.argtypes = [vp, ctypes.POINTER(Unit), u32, vp, sz, vp, sz, ctypes.POINTER(Result)]
     L.milzma_multi_decode_units.argtypes = [vp, ctypes.POINTER(Unit), u32, ctypes.POINTER(u32), ctypes.POINTER(vp),
                                             ctypes.POINTER(vp), ctypes.POINTER(Result)]
+    L.milzma_multi_decode_units_rooted.argtypes = [vp, u32, ctypes.POINTER(Unit), u32, vp, vp, ctypes.POINTER(Result)]
+    L.milzma_multi_last_transfer_ms.restype = None
+    L.milzma_multi_last_transfer_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.milzma_multi_lzma_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz),
                                                      ctypes.POINTER(_COptions), ctypes.POINTER(_COutput)]
     L.milzma_multi_lzma2_decompress_batch.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(_COutput)]
@@ -518,6 +522,17 @@ class MultiContext:
         if lib().milzma_multi_decode_units(self._h, units, n, dev, pin, pout, results) != OK:
             raise InfraError("milzma_multi_decode_units: " + self.last_error())
         return results
+
+    def decode_units_rooted(self, root, units, d_in, d_out):
+        """milzma_multi_decode_units_rooted: input and output resident on device index `root`; the other devices get their shares
+        device to device.  Returns (results, (scatter_ms, decode_ms, gather_ms))."""
+        n = len(units)
+        results = (Result * n)()
+        if lib().milzma_multi_decode_units_rooted(self._h, root, units, n, ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), results) != OK:
+            raise InfraError("milzma_multi_decode_units_rooted: " + self.last_error())
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        lib().milzma_multi_last_transfer_ms(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return results, (a.value, b.value, c.value)
 
     def _batch(self, fn, datas, options=None, with_options=False):
         n = len(datas)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cinttypes>
 #include <condition_variable>
@@ -57,8 +58,8 @@ struct UploadTurn {  // whose upload may use the PCIe link now: groups of one ca
 struct milzma_ctx {
   int device = 0;
   std::string err;
-  DevBuf units, order, results, scratch, in, out, pack, crc, flags, slice_q, slice_ctx;  // pack: finished outputs gathered for the download  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
-  PinBuf pin_in, pin_out, pin_small;
+  DevBuf units, order, results, scratch, in, out, pack, crc, flags, slice_q, slice_ctx, hostptrs;  // pack: finished outputs gathered for the download  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
+  PinBuf pin_in, pin_out, pin_small, pin_lead;  // pin_lead: the units' first bytes, gathered for a streamed launch
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // milzma_decode_units_async: what is in flight until milzma_decode_units_wait
@@ -75,6 +76,17 @@ struct milzma_ctx {
   // call may resume them as long as it is a RESUME with the same n); any other decode call on the context gives the parking lot up
   bool parked_valid = false;
   uint32_t parked_n = 0;
+  // Streamed launches (the whole-file calls' progressive download): a caller that sets stream_span / stream_spans before the async
+  // half asks for the batch's ONE fast launch to run time-sliced with span counters (kernels.h); stream_active says it happened.
+  // progress: kMaxSpans counters in mapped host memory, written by the device, polled by SpanPump.
+  static constexpr uint32_t kMaxSpans = 64;
+  uint32_t* progress = nullptr;
+  uint32_t* progress_dev = nullptr;
+  uint32_t stream_span = 0, stream_spans = 0;
+  uint8_t* stream_host = nullptr;   // where the waves of a streamed launch write their output: pin_out, as the device sees it
+  const uint64_t* stream_ptrs = nullptr;  // ... or, per unit, the caller's own page-locked result buffer (device array in `hostptrs`)
+  bool stream_in_host = false;      // ... and its input is read from host memory that is still being filled (progress[kMaxSpans] = ready)
+  bool stream_active = false;
   PinBuf pin_results;
   hipStream_t copy_stream = nullptr;    // chunked staging copies of the whole-file batch entry points
   hipStream_t work_stream = nullptr;    // decode launches of the whole-file / host-buffer entry points: the context's own
@@ -334,6 +346,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   dev_release(ctx->in);
   dev_release(ctx->out);
   dev_release(ctx->pack);
+  dev_release(ctx->hostptrs);
   dev_release(ctx->crc);
   dev_release(ctx->flags);
   dev_release(ctx->slice_q);
@@ -341,12 +354,14 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   pin_release(ctx->pin_in);
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
+  pin_release(ctx->pin_lead);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
   pin_release(ctx->pin_results);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->progress) (void)hipHostFree(ctx->progress);
   delete ctx;
 }
 
@@ -371,12 +386,20 @@ namespace {
 
 struct OutHdr {
   uint64_t cap;
-  uint64_t pad;  // (keeps the payload 16-byte aligned)
+  uint64_t pinned;  // 1: page-locked (hipHostMalloc), a streamed launch writes it from the device; (also keeps the payload 16-byte aligned)
 };
+
+void hdr_free(OutHdr* h) {
+  if (h->pinned)
+    (void)hipHostFree(h);
+  else
+    free(h);
+}
 
 struct OutPool {
   std::mutex mu;
   std::map<size_t, std::vector<OutHdr*>> free_by_cap;   // ordered: a request takes the smallest class that holds it
+  std::map<size_t, std::vector<OutHdr*>> free_pinned;   // the same for page-locked buffers (never handed out for ordinary requests)
   std::unordered_set<const void*> live;                  // payload pointers handed out and not yet freed
   size_t held = 0, live_bytes = 0, peak_live = 0, limit = size_t(8) << 30;
   OutPool() {
@@ -385,19 +408,21 @@ struct OutPool {
   ~OutPool() {
     for (auto& kv : free_by_cap)
       for (OutHdr* h : kv.second) free(h);
+    // (page-locked buffers still pooled at exit are left to the process's end: the HIP runtime may be gone already)
   }
   // (mu held) frees pooled buffers, largest classes first, until at most `keep` bytes rest in the pool
   void trim_locked(size_t keep) {
-    for (auto it = free_by_cap.end(); held > keep && it != free_by_cap.begin();) {
-      --it;
-      while (held > keep && !it->second.empty()) {
-        OutHdr* h = it->second.back();
-        it->second.pop_back();
-        held -= size_t(h->cap);
-        free(h);
+    for (auto* m : {&free_pinned, &free_by_cap})
+      for (auto it = m->end(); held > keep && it != m->begin();) {
+        --it;
+        while (held > keep && !it->second.empty()) {
+          OutHdr* h = it->second.back();
+          it->second.pop_back();
+          held -= size_t(h->cap);
+          hdr_free(h);
+        }
+        if (it->second.empty()) it = m->erase(it);
       }
-      if (it->second.empty()) it = free_by_cap.erase(it);
-    }
   }
 };
 OutPool& out_pool() {
@@ -415,32 +440,47 @@ size_t out_class(size_t n) {  // capacity class: powers of two up to 64 KiB, mul
   return (n + 0xFFFF) & ~size_t(0xFFFF);
 }
 
-uint8_t* out_alloc(size_t n) {
+// pinned: page-locked memory a streamed launch can write from the device (hipHostMalloc, portable: any device of the node); such
+// buffers are handed out to the caller like any other and come back through milzma_free into a pool of their own
+uint8_t* out_alloc(size_t n, bool pinned = false) {
   const size_t cap = out_class(n);
   OutPool& p = out_pool();
   OutHdr* h = nullptr;
   try {
-    std::lock_guard<std::mutex> lock(p.mu);
-    // best fit: the smallest pooled class that holds the request, as long as it wastes at most half of itself (a workload of
-    // varied sizes reuses what it has instead of filling the pool with classes that never match exactly)
-    auto it = p.free_by_cap.lower_bound(cap);
-    while (it != p.free_by_cap.end() && it->second.empty()) it = p.free_by_cap.erase(it);
-    if (it != p.free_by_cap.end() && it->first <= std::max(cap * 2, cap + (size_t(1) << 16))) {
-      h = it->second.back();
-      it->second.pop_back();
-      p.held -= size_t(h->cap);
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      // best fit: the smallest pooled class that holds the request, as long as it wastes at most half of itself (a workload of
+      // varied sizes reuses what it has instead of filling the pool with classes that never match exactly)
+      auto& m = pinned ? p.free_pinned : p.free_by_cap;
+      auto it = m.lower_bound(cap);
+      while (it != m.end() && it->second.empty()) it = m.erase(it);
+      if (it != m.end() && it->first <= std::max(cap * 2, cap + (size_t(1) << 16))) {
+        h = it->second.back();
+        it->second.pop_back();
+        p.held -= size_t(h->cap);
+      }
     }
-    if (!h) {
-      h = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
-      if (!h) return nullptr;
+    if (!h) {  // (allocated outside the lock: pinning a MiB takes its time, and thousands are wanted at once)
+      if (pinned) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, sizeof(OutHdr) + cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+          (void)hipGetLastError();
+          return nullptr;
+        }
+        h = static_cast<OutHdr*>(q);
+      } else {
+        h = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
+        if (!h) return nullptr;
+      }
       h->cap = cap;
-      h->pad = 0;
+      h->pinned = pinned ? 1 : 0;
     }
+    std::lock_guard<std::mutex> lock(p.mu);
     p.live.insert(h + 1);
     p.live_bytes += size_t(h->cap);
     p.peak_live = std::max(p.peak_live, p.live_bytes);
   } catch (const std::bad_alloc&) {  // (the registry could not grow: the buffer is not handed out)
-    free(h);
+    if (h) hdr_free(h);
     return nullptr;
   }
   return reinterpret_cast<uint8_t*>(h + 1);
@@ -461,14 +501,14 @@ extern "C" void milzma_free(void* ptr) {
     p.live_bytes -= size_t(h->cap);
     if (p.held + h->cap <= std::min(p.limit, p.peak_live)) {
       try {
-        p.free_by_cap[size_t(h->cap)].push_back(h);
+        (h->pinned ? p.free_pinned : p.free_by_cap)[size_t(h->cap)].push_back(h);
         p.held += size_t(h->cap);
         return;
       } catch (const std::bad_alloc&) {
       }
     }
   }
-  free(h);
+  hdr_free(h);
 }
 
 extern "C" size_t milzma_pool_trim(size_t keep_bytes) {
@@ -506,6 +546,23 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   return kLitSpill;
 }
 
+// the span counters (+ the input-ready word behind them) of streamed launches: host memory the device can reach
+bool ensure_progress(milzma_ctx* ctx) {
+  if (ctx->progress) return true;
+  void* hp = nullptr;
+  void* dp = nullptr;
+  if (hipHostMalloc(&hp, (milzma_ctx::kMaxSpans + 16) * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+      hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+    ctx->progress = static_cast<uint32_t*>(hp);
+    ctx->progress_dev = static_cast<uint32_t*>(dp);
+    memset(hp, 0, (milzma_ctx::kMaxSpans + 16) * sizeof(uint32_t));
+    return true;
+  }
+  (void)hipGetLastError();
+  if (hp) (void)hipHostFree(hp);
+  return false;
+}
+
 // Launches `order` (unit indices) in class `cls`; kernel time is accumulated into ctx.
 bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& order, uint32_t order_base,
                   const uint8_t* d_in, uint8_t* d_out, hipStream_t stream, bool grow = false, bool resume = false) {
@@ -540,7 +597,8 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     if (cls == kFast || cls == kFastLc4) {
       const uint32_t resident = fast_resident_blocks(cls == kFastLc4, ctx->lds_pad);
       // (growable output is a feature of the time-sliced kernel: it is the one that can park a unit)
-      sliced = grow || ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
+      const bool want_stream = ctx->stream_span != 0 && (ctx->stream_host != nullptr || ctx->stream_ptrs != nullptr) && m == ctx->pend_n && !resume;  // (the launch is the whole batch: the counters reach n)
+      sliced = grow || want_stream || ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
       if (sliced) {
         uint64_t entries = m, longest = 0;
         const uint64_t least = std::max<uint32_t>(1u, ctx->slice_quantum / 4u * 3u);  // (a turn is 0.75 .. 1.5 quanta)
@@ -554,7 +612,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
         const std::string keep = ctx->err;
         // Not worth it / not to be had: units that all end within their first turn are never parked (the hardware's own block dispatch
         // does as well for them, without a parking lot of 20-34 KB per unit); a parking lot beyond a quarter of the free memory.
-        if ((ctx->slice_mode == 0 && longest <= least && !grow) || entries > 0x7FFFFFF0ull ||
+        if ((ctx->slice_mode == 0 && longest <= least && !grow && !want_stream) || entries > 0x7FFFFFF0ull ||
             (ctx_bytes > ctx->slice_ctx.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && ctx_bytes > (free_b + ctx->slice_ctx.cap) / 4) ||
             !dev_reserve(ctx, ctx->slice_q, slice_queue_bytes(uint32_t(entries))) || !dev_reserve(ctx, ctx->slice_ctx, ctx_bytes)) {
           sliced = false;
@@ -565,12 +623,21 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
           ctx->err = keep;
         }
         cap = uint32_t(entries);
+        if (sliced && want_stream) {
+          if (ensure_progress(ctx)) {
+            memset(ctx->progress, 0, milzma_ctx::kMaxSpans * sizeof(uint32_t));
+            ctx->stream_active = true;
+          }
+        }
       }
     }
     const hipError_t le = sliced
                               ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                                    static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
-                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow)
+                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow, ctx->stream_span, ctx->stream_spans,
+                                                   ctx->stream_active ? ctx->progress_dev : nullptr, ctx->stream_active ? ctx->stream_host : nullptr,
+                                                   ctx->stream_active && ctx->stream_in_host ? ctx->progress_dev + milzma_ctx::kMaxSpans : nullptr,
+                                                   ctx->stream_active ? ctx->stream_ptrs : nullptr)
                           : cls == kFast || cls == kFastLc4
                               ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
                                             static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
@@ -623,6 +690,7 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   ctx->ev_used = 0;
   ctx->pend_n = n;
   ctx->pend_flags = (grow ? MILZMA_DECODE_GROW : 0u) | (resume ? MILZMA_DECODE_RESUME : 0u);
+  ctx->stream_active = false;
   ctx->pending = true;
   if (n == 0) return MILZMA_OK;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -889,6 +957,7 @@ extern "C" int milzma_result_message(const milzma_result* r, uint32_t unit_kind,
     case MILZMA_ST_NEED_LCLP: return render(msg, cap, MILZMA_INFRA_ERROR, "literal table class too small for lc+lp=%llu", a);
     case MILZMA_ST_BAD_UNIT: return render(msg, cap, MILZMA_INFRA_ERROR, "bad unit descriptor");
     case MILZMA_ST_NEED_GENERIC: return render(msg, cap, MILZMA_INFRA_ERROR, "properties outside the fast kernel's class");
+    case MILZMA_ST_NEED_RERUN: return render(msg, cap, MILZMA_INFRA_ERROR, "unit outran its input upload");
     default: return render(msg, cap, MILZMA_INFRA_ERROR, "unknown status %u", r->status);
   }
 }
@@ -1218,6 +1287,83 @@ bool regrow_parked(milzma_ctx* ctx, std::vector<milzma_unit>& units, const std::
   return true;
 }
 
+// the per-unit host destinations of a streamed launch (kernels.h: host_ptrs) -> ctx->hostptrs
+bool upload_host_ptrs(milzma_ctx* ctx, const std::vector<uint64_t>& ptrs, hipStream_t ws) {
+  const size_t bytes = ptrs.size() * sizeof(uint64_t);
+  return dev_reserve(ctx, ctx->hostptrs, bytes) && hip_ok(ctx, hipMemcpyAsync(ctx->hostptrs.p, ptrs.data(), bytes, hipMemcpyHostToDevice, ws), "H2D pointers") &&
+         hip_ok(ctx, hipStreamSynchronize(ws), "hipStreamSynchronize");
+}
+
+// One streamed launch per device at a time: its persistent waves take the whole chip for the length of the call, so a second one
+// (another context with a batch in flight: the *_batch_async pairs) would only fight it for the SIMDs -- that call runs the classic
+// way instead (its copies ride under the first one's kernel: 2 x 4096 files in flight measured 11.9 GB/s streamed + streamed
+// against 13.6 classic + classic, profiles/r04_batch_api.txt).
+std::atomic<int> g_streamed_in_flight[64];
+struct StreamedSlot {
+  int dev = -1;
+  bool try_take(int device) {
+    if (device < 0 || device >= 64) return false;
+    if (g_streamed_in_flight[device].fetch_add(1) != 0) {
+      g_streamed_in_flight[device].fetch_sub(1);
+      return false;
+    }
+    dev = device;
+    return true;
+  }
+  ~StreamedSlot() {
+    if (dev >= 0) g_streamed_in_flight[dev].fetch_sub(1);
+  }
+};
+
+bool pinned_results_wanted() {
+  static const bool off = getenv("MILZMA_PINNED_OUT") && !strcmp(getenv("MILZMA_PINNED_OUT"), "0");
+  return !off;
+}
+
+// Two-part upload for streamed launches.  A decode kernel needs the FIRST bytes of every unit when it starts and the rest only as
+// fast as it decodes (6 GB/s for the whole chip, against 50 on the link), so:
+//   begin:  the first stream_lead_bytes of every unit (its "lead") are gathered into one page-locked block, go up with one copy and
+//           are put in place by one move kernel -- a few ms, then the kernel can be launched with in_ready = 0;
+//   finish: while it runs, the complete input is gathered into the page-locked input buffer and sent in large consecutive pieces
+//           (the copy engines work beside the kernel).  The pieces overwrite the leads with the bytes they already hold, which is
+//           harmless; when the last piece has landed the ready word is set.  A wave that would come within a turn's reach of the end
+//           of its lead before that waits (kernels.h: in_ready) -- a safety net, not the normal course.
+// src(k): where unit k's input bytes are in the caller's memory.
+template <class Src>
+bool upload_leads(milzma_ctx* ctx, const std::vector<milzma_unit>& units, Src src, hipStream_t ws) {
+  const uint32_t nu = uint32_t(units.size());
+  std::vector<uint64_t> so(nu), dof(nu), ln(nu);
+  size_t total = 0;
+  for (uint32_t k = 0; k < nu; k++) {
+    ln[k] = std::min<uint64_t>(units[k].in_len, stream_lead_bytes(uint32_t(std::min<uint64_t>(units[k].in_len, 0xFFFFFF00u))));
+    so[k] = total;
+    dof[k] = units[k].in_off;
+    total += round_up(size_t(ln[k]), 256);
+  }
+  if (!pin_reserve(ctx, ctx->pin_lead, total) || !dev_reserve(ctx, ctx->pack, total + 512)) return false;
+  uint8_t* h = static_cast<uint8_t*>(ctx->pin_lead.p);
+  parallel_for(nu, [&](size_t k) { memcpy(h + so[k], src(k), size_t(ln[k])); });
+  return hip_ok(ctx, hipMemcpyAsync(ctx->pack.p, h, total, hipMemcpyHostToDevice, ws), "H2D leads") &&
+         move_units_impl(ctx, nu, ctx->pack.p, so.data(), ctx->in.p, dof.data(), ln.data(), ws) == MILZMA_OK;
+}
+
+// bounds: ascending offsets into the input buffer (pieces); fill(g) gathers piece g's bytes [bounds[g], bounds[g + 1]) into hin
+template <class F>
+bool upload_rest(milzma_ctx* ctx, uint8_t* hin, const std::vector<size_t>& bounds, F fill) {
+  ChunkedCopy cc;
+  bool ok = cc.stream_ready(ctx);
+  for (size_t g = 0; ok && g + 1 < bounds.size(); g++) {
+    fill(g);
+    const size_t lo = bounds[g], hi = bounds[g + 1];
+    if (hi > lo)
+      ok = hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->in.p) + lo, hin + lo, hi - lo, hipMemcpyHostToDevice, ctx->copy_stream), "H2D input");
+  }
+  ok = ok && hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize");
+  // (ready also when a copy failed: the waves must not wait for ever -- the caller fails the call)
+  __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 1u, __ATOMIC_RELEASE);
+  return ok;
+}
+
 // One unit through the device with host buffers.  Its output slice grows while the stream needs more room: a unit of the fast
 // kernels is parked at the end of its slice and resumed in a larger one (nothing is decoded twice); a unit of the generic kernel
 // (lc + lp > 4) reports a plain OUT_FULL and starts over with four times the room.  `cap_hint` is the first slice size to try.
@@ -1427,13 +1573,46 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   };
   if (!ctx) return fail_all();
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail_all();
-  if (!pin_reserve(ctx, ctx->pin_in, in_total) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
+  // Streamed round 0 (below) for batches it pays for: many files of about one size, all in the fast kernel's class.  Their output
+  // slices then sit at ONE pitch (span cuts are computed from the unit's index and the pitch alone).
+  struct {
+    size_t pitch = 0, span = 0;
+    uint32_t spans = 0;
+  } geo;
+  StreamedSlot streamed_slot;
+  {
+    static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
+    size_t max_cap = 0;
+    bool all_fast = ctx->use_fast && !off && units.size() >= 256 && out_total >= (size_t(256) << 20);
+    for (const milzma_unit& u : units) {
+      max_cap = std::max(max_cap, size_t(u.out_cap));
+      all_fast = all_fast && classify(ctx, u) == kFast;
+    }
+    const size_t pitch = round_up(max_cap, 256);
+    if (all_fast && pitch * units.size() <= out_total + out_total / 4 && in_total + pitch * units.size() <= budget &&
+        streamed_slot.try_take(ctx->device)) {
+      size_t span = size_t(64) << 10;
+      if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
+      while ((pitch + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
+      geo.pitch = pitch;
+      geo.span = span;
+      geo.spans = uint32_t((pitch + span + span - 1) / span);
+      out_total = 0;
+      for (milzma_unit& u : units) {
+        u.out_off = out_total;
+        out_total += pitch;
+      }
+    }
+  }
+  // (+ 512: the kernels fetch whole aligned windows, and a streamed launch reads this buffer itself)
+  if (!pin_reserve(ctx, ctx->pin_in, in_total + 512) || !pin_reserve(ctx, ctx->pin_out, out_total) ||
       !dev_reserve(ctx, ctx->in, in_total + 512) || !dev_reserve(ctx, ctx->out, out_total + 512)) {
     for (uint32_t i : owner) single(i);  // the batch's staging cannot be had: one stream at a time
     return finish_alone();
   }
   uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-  {
+  const void* d_input = ctx->in.p;  // where the decode calls find the compressed bytes: the device copy, or (streamed) the host buffer itself
+  const auto upload = [&]() {
     // eight groups of streams: the gather of one group overlaps the transfer of the one before
     const size_t groups = std::min<size_t>(8, units.size());
     std::vector<size_t> first(groups + 1), bounds(groups + 1);
@@ -1441,14 +1620,14 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       first[g] = units.size() * g / groups;
       bounds[g] = g == groups ? in_total : size_t(units[first[g]].in_off);
     }
-    if (!staged_h2d(ctx, ctx->in.p, hin, bounds, [&](size_t g) {
-          parallel_for(first[g + 1] - first[g], [&](size_t k0) {
-            const size_t k = first[g] + k0;
-            memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
-          });
-        }))
-      return fail_all();
-  }
+    return staged_h2d(ctx, ctx->in.p, hin, bounds, [&](size_t g) {
+      parallel_for(first[g + 1] - first[g], [&](size_t k0) {
+        const size_t k = first[g] + k0;
+        memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+      });
+    });
+  };
+  if (!geo.spans && !upload()) return fail_all();
   const uint32_t kind = lzma2 ? MILZMA_KIND_LZMA2 : MILZMA_KIND_RAW_LZMA;
   // Rounds.  A unit whose guessed output slice was too small (unknown-size streams: every .lzma that liblzma writes) is PARKED at
   // the end of its slice by the decode kernel, given a larger slice -- what it has produced moves there on the device -- and
@@ -1463,10 +1642,157 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   const auto give_up = [&](const std::vector<uint32_t>& list) {
     for (uint32_t k : list) infra(ctx, &outs[owner[k]]);
   };
-  for (bool first = true; !active.empty(); first = false) {
+  bool first = true;
+  if (geo.spans) {
+    // Round 0, streamed: one time-sliced launch whose waves write their output to the page-locked host buffer themselves, span by
+    // span, while they decode (kernels.h); this thread waits for the kernel, a second one hands every span of every file over to the
+    // caller's buffers as the span counters come in.  When the kernel ends, all that is left is the last span's hand-over.
+    // The files' result buffers come page-locked from the pool: the waves write every span straight into the buffer the caller will
+    // get (kernels.h: host_ptrs) and the host copies nothing.  If page-locked memory cannot be had, ordinary buffers are filled from
+    // the page-locked staging buffer by a host thread, span by span.
+    std::vector<uint8_t*> bufs(nu, nullptr);
+    std::atomic<int> alloc_failed{0};
+    bool direct = pinned_results_wanted();
+    if (direct) {
+      parallel_for(nu, [&](size_t k) {
+        bufs[k] = out_alloc(size_t(units[k].out_cap), true);
+        if (!bufs[k]) alloc_failed = 1;
+      });
+      if (alloc_failed) {
+        for (uint8_t*& b : bufs) {
+          milzma_free(b);
+          b = nullptr;
+        }
+        alloc_failed = 0;
+        direct = false;
+      }
+    }
+    if (!direct)
+      parallel_for(nu, [&](size_t k) {
+        bufs[k] = out_alloc(size_t(units[k].out_cap));
+        if (!bufs[k]) alloc_failed = 1;
+      });
+    // The input goes up in two parts (upload_leads / upload_rest above): the leads before the launch, everything while it runs.
+    void* host_dev = nullptr;
+    bool ok = !alloc_failed && ensure_progress(ctx);
+    if (ok && direct) {
+      std::vector<uint64_t> ptrs(size_t(nu) * 2);
+      for (uint32_t k = 0; k < nu; k++) {
+        ptrs[2 * size_t(k)] = uint64_t(reinterpret_cast<uintptr_t>(bufs[k]));
+        ptrs[2 * size_t(k) + 1] = units[k].out_cap;
+      }
+      ok = upload_host_ptrs(ctx, ptrs, work_stream(ctx));
+    } else if (ok) {
+      ok = pin_reserve(ctx, ctx->pin_out, out_total) && hipHostGetDevicePointer(&host_dev, ctx->pin_out.p, 0) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    bool input_up = false;
+    if (ok) {
+      trace_mark(ctx, "streamed: leads");
+      ok = upload_leads(ctx, units, [&](size_t k) { return ins[owner[k]] + hdr[owner[k]]; }, work_stream(ctx));
+    }
+    if (ok) {
+      __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 0u, __ATOMIC_RELEASE);
+      ctx->stream_span = uint32_t(geo.span);
+      ctx->stream_spans = geo.spans;
+      ctx->stream_host = static_cast<uint8_t*>(host_dev);
+      ctx->stream_ptrs = direct ? static_cast<const uint64_t*>(ctx->hostptrs.p) : nullptr;
+      ctx->stream_in_host = true;
+      trace_mark(ctx, "streamed: launch");
+      ok = milzma_decode_units_async_impl(ctx, units.data(), nu, ctx->in.p, ctx->out.p, work_stream(ctx), MILZMA_DECODE_GROW, nullptr) == MILZMA_OK;
+      ctx->stream_span = ctx->stream_spans = 0;
+      ctx->stream_host = nullptr;
+      ctx->stream_ptrs = nullptr;
+      ctx->stream_in_host = false;
+      // the whole input, in sixteen pieces, whatever became of the launch (the classic rounds want it too)
+      const size_t pieces = std::min<size_t>(16, nu);
+      std::vector<size_t> first_u(pieces + 1), bounds(pieces + 1);
+      for (size_t g = 0; g <= pieces; g++) {
+        first_u[g] = nu * g / pieces;
+        bounds[g] = g == pieces ? in_total : size_t(units[first_u[g]].in_off);
+      }
+      input_up = upload_rest(ctx, hin, bounds, [&](size_t g) {
+        parallel_for(first_u[g + 1] - first_u[g], [&](size_t k0) {
+          const size_t k = first_u[g] + k0;
+          memcpy(hin + units[k].in_off, ins[owner[k]] + hdr[owner[k]], size_t(units[k].in_len));
+        });
+      });
+      trace_mark(ctx, "streamed: input complete");
+      if (!input_up) {
+        if (ok) (void)milzma_decode_units_wait_impl(ctx, res.data());
+        for (uint8_t* b : bufs) milzma_free(b);
+        give_up(active);
+        finish_alone();
+        return MILZMA_INFRA_ERROR;
+      }
+    }
+    if (ok && ctx->stream_active) {
+      std::atomic<bool> kernel_done{false};
+      const uint8_t* hout = static_cast<const uint8_t*>(ctx->pin_out.p);
+      std::thread consumer([&] {
+        if (direct) return;   // (the waves fill the result buffers themselves)
+        for (uint32_t sp = 0; sp < geo.spans; sp++) {
+          while (__atomic_load_n(&ctx->progress[sp], __ATOMIC_ACQUIRE) < nu && !kernel_done.load(std::memory_order_acquire))
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+          parallel_for(nu, [&](size_t k) {
+            const size_t phase = (k & 15u) * (geo.span >> 4), cap = size_t(units[k].out_cap);
+            const size_t lo = sp * geo.span > phase ? sp * geo.span - phase : 0, hi = std::min(cap, (sp + 1) * geo.span - phase);
+            if (lo < hi) memcpy(bufs[k] + lo, hout + size_t(units[k].out_off) + lo, hi - lo);
+          });
+        }
+      });
+      const int wr = milzma_decode_units_wait_impl(ctx, res.data());
+      kernel_done.store(true, std::memory_order_release);
+      consumer.join();
+      trace_mark(ctx, "streamed decode + hand-over: done");
+      if (wr != MILZMA_OK) {
+        for (uint8_t* b : bufs) milzma_free(b);
+        give_up(active);
+        finish_alone();
+        return MILZMA_INFRA_ERROR;
+      }
+      std::vector<uint32_t> parked;
+      for (uint32_t k = 0; k < nu; k++) {
+        const milzma_result& r = res[k];
+        const bool more_room = units[k].out_cap < MILZMA_MAX_UNIT_BYTES;
+        if (is_parked(r) && more_room) {
+          parked.push_back(k);
+        } else if ((r.status == MILZMA_ST_OUT_FULL && !is_parked(r) && more_room) || r.status == MILZMA_ST_NEED_RERUN) {
+          restart.push_back(k);   // (NEED_RERUN: it outran the second part of the upload; its slice is big enough, more does not hurt)
+        } else {
+          milzma_output* o = &outs[owner[k]];
+          milzma_result rr = r;
+          if (is_parked(rr)) rr.err_a = 0;
+          o->in_consumed = hdr[owner[k]] + size_t(rr.in_consumed);
+          o->data = bufs[k];
+          o->len = size_t(std::min<uint64_t>(rr.out_flushed, units[k].out_cap));
+          o->kind = milzma_result_message(&rr, kind, o->msg, sizeof o->msg);
+          bufs[k] = nullptr;
+        }
+      }
+      for (uint8_t* b : bufs) milzma_free(b);
+      size_t ob = 0;
+      if (!parked.empty() && !regrow_parked(ctx, units, res, parked, work_stream(ctx), &ob)) {
+        give_up(parked);
+        give_up(restart);
+        finish_alone();
+        return MILZMA_INFRA_ERROR;
+      }
+      if (!parked.empty()) out_bytes = ob;
+      active.swap(parked);
+      first = false;
+    } else {
+      // not to be had (no mapped memory, or the launch could not be time-sliced): the batch in flight, if any, is collected and the
+      // classic rounds below do the work -- nothing has been handed over yet
+      if (ok) (void)milzma_decode_units_wait_impl(ctx, res.data());
+      for (uint8_t* b : bufs) milzma_free(b);
+      if (!input_up && !upload()) return fail_all();  // (whatever part of the input went up: all of it now)
+    }
+  }
+  for (; !active.empty(); first = false) {
     std::vector<uint32_t> parked;
     {
-      if (milzma_decode_units_impl(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), work_stream(ctx),
+      if (milzma_decode_units_impl(ctx, units.data(), nu, d_input, ctx->out.p, res.data(), work_stream(ctx),
                                    first ? MILZMA_DECODE_GROW : MILZMA_DECODE_RESUME) != MILZMA_OK) {
         give_up(active);
         give_up(restart);
@@ -1552,7 +1878,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     std::vector<milzma_result> r(sub.size());
     ChunkedCopy d2h;
     if (!pin_reserve(ctx, ctx->pin_out, bytes) || !dev_reserve(ctx, ctx->out, bytes + 512) ||
-        milzma_decode_units_impl(ctx, sub.data(), uint32_t(sub.size()), ctx->in.p, ctx->out.p, r.data(), work_stream(ctx), 0) != MILZMA_OK ||
+        milzma_decode_units_impl(ctx, sub.data(), uint32_t(sub.size()), d_input, ctx->out.p, r.data(), work_stream(ctx), 0) != MILZMA_OK ||
         !d2h.start_d2h(ctx, ctx->pin_out.p, ctx->out.p, bytes)) {
       give_up(restart);
       finish_alone();
@@ -1682,6 +2008,7 @@ struct Payload {
   milzma_result res;
   const uint8_t* data = nullptr;  // res.out_len bytes (valid when res.status == OK)
   std::vector<uint8_t> own;       // backing store when decoded on demand
+  size_t prefilled_at = SIZE_MAX; // the payload already sits at this offset of the file's output buffer (OutBuf::append)
   bool has_crc = false;           // crc32 / crc64 of data were computed on the GPU (milzma_crc_units' kernel)
   uint32_t crc32 = 0;
   uint64_t crc64 = 0;
@@ -1698,7 +2025,15 @@ struct Record {
 struct OutBuf {
   uint8_t* p = nullptr;
   size_t n = 0, cap = 0;
-  ~OutBuf() { milzma_free(p); }
+  bool moved = false;  // the buffer was reallocated: whatever had been put beyond n beforehand is gone
+  // hold_first: payloads may point INTO the first buffer (a streamed launch wrote them there): if the file outgrows it, it is kept
+  // (in `keep`) until this object goes, so that those pointers stay good
+  bool hold_first = false;
+  uint8_t* keep = nullptr;
+  ~OutBuf() {
+    milzma_free(p);
+    milzma_free(keep);
+  }
   bool reserve(size_t want) {
     if (want <= cap) return true;
     size_t c = std::max(want, cap + cap / 2);
@@ -1706,12 +2041,31 @@ struct OutBuf {
     uint8_t* q = out_alloc(c);
     if (!q) return false;
     if (n) memcpy(q, p, n);
-    milzma_free(p);
+    if (hold_first && !keep)
+      keep = p;
+    else
+      milzma_free(p);
+    moved = p != nullptr;
     p = q;
     cap = c;
     return true;
   }
-  bool append(const uint8_t* src, size_t len) {
+  // the first allocation page-locked (a streamed launch writes into it from the device); growth moves to ordinary memory
+  bool reserve_pinned(size_t want) {
+    if (p) return reserve(want);
+    const size_t c = out_class(std::max<size_t>(want, 4096));
+    p = out_alloc(c, true);
+    if (!p) return false;
+    cap = c;
+    return true;
+  }
+  // prefilled_at: the same bytes were put at that offset of this buffer beforehand (streamed xz batches copy every block's spans to
+  // their place in the file's buffer while the kernel runs): if that is where the file stands, they are taken as they are
+  bool append(const uint8_t* src, size_t len, size_t prefilled_at = SIZE_MAX) {
+    if (prefilled_at == n && p && !moved && n + len <= cap) {
+      n += len;
+      return true;
+    }
     if (!reserve(n + len)) return false;
     if (len) memcpy(p + n, src, len);
     n += len;
@@ -1791,7 +2145,8 @@ int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, OutBuf& output, i
     }
     default: return out_fail(o, MILZMA_XZ_ERROR, "Unsupported SHA-256 checksum (not yet implemented)");
   }
-  if (!output.append(cur.data, size_t(unpacked_size))) return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
+  if (!output.append(cur.data, size_t(unpacked_size), bh.num_filters == 1 ? cur.prefilled_at : SIZE_MAX))
+    return out_fail(o, MILZMA_INFRA_ERROR, "out of memory");
   records.push_back(Record{uint64_t(c.pos - block_start - padding), unpacked_size});
   return MILZMA_OK;
 }
@@ -1834,11 +2189,19 @@ int check_index(Cursor& c, size_t index_start, const std::vector<Record>& record
 
 // xz::decode_stream (src/decode/xz.rs:18-94) + StreamHeader::parse (src/xz/header.rs:20-51)
 int xz_walk(milzma_ctx* ctx, const uint8_t* in, size_t in_len, const PayloadFn& decode, milzma_output* o,
-            size_t out_hint = 0) {
+            size_t out_hint = 0, OutBuf* prefilled = nullptr) {
   static const uint8_t kMagic[6] = {0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00};
   out_reset(o);
   Cursor c{in, 0, in_len};
   OutBuf output;
+  if (prefilled && prefilled->p) {  // (the file's buffer with its blocks' payloads already in place: see OutBuf::append)
+    output.p = prefilled->p;
+    output.cap = prefilled->cap;
+    output.moved = prefilled->moved;
+    output.hold_first = true;
+    prefilled->p = nullptr;
+    prefilled->cap = 0;
+  }
   (void)output.reserve(std::max<size_t>(out_hint, 1));
   std::vector<Record> records;
   int r = MILZMA_OK;
@@ -1995,6 +2358,8 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   struct Ref {
     uint32_t file;
     size_t data_off;
+    size_t blk_off;    // where the block's output starts in its file's output (sum of the Index's sizes of the blocks before it)
+    size_t unpacked;   // the Index's size of the block's output
   };
   std::vector<milzma_unit> units;
   std::vector<Ref> refs;
@@ -2018,9 +2383,9 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
       u.out_off = out_total;
       u.out_cap = round_up(size_t(b.unpacked) + 16, 256);
       out_total += size_t(u.out_cap);
-      file_out_hint[i] += size_t(b.unpacked);
       units.push_back(u);
-      refs.push_back(Ref{i, b.data_off});
+      refs.push_back(Ref{i, b.data_off, file_out_hint[i], size_t(b.unpacked)});
+      file_out_hint[i] += size_t(b.unpacked);
     }
     if (!blocks.empty()) {
       planned[i] = 1;
@@ -2035,6 +2400,38 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   const uint8_t* hout = nullptr;
   const uint8_t* parts = nullptr;
   ChunkedCopy d2h;
+  // Streamed form (many blocks of about one size -- the usual .xz: 1 .. 8 MiB blocks): ONE time-sliced launch whose waves write
+  // their output to the page-locked host buffer themselves, span by span (kernels.h), while a host thread copies every span that
+  // has arrived to its place in the FILE's output buffer (block offsets follow from the Index): when the kernel ends the files'
+  // buffers are nearly complete and the walks below append without copying (OutBuf::append, prefilled_at).
+  struct {
+    size_t pitch = 0, span = 0;
+    uint32_t spans = 0;
+  } geo;
+  std::vector<OutBuf> filebuf(n);
+  StreamedSlot streamed_slot;
+  bool streamed_done = false, streamed_direct = false;
+  std::unordered_map<size_t, std::vector<uint8_t>> longer;   // blocks that came out LONGER than the Index says (their place holds only the Index's size)
+  if (nu) {
+    static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
+    size_t max_cap = 0;
+    for (const milzma_unit& u : units) max_cap = std::max(max_cap, size_t(u.out_cap));
+    const size_t pitch = round_up(max_cap, 256);
+    if (ctx->use_fast && !off && nu >= 256 && out_total >= (size_t(256) << 20) && pitch * nu <= out_total + out_total / 4 &&
+        in_total + pitch * nu <= budget && streamed_slot.try_take(ctx->device)) {
+      size_t span = size_t(64) << 10;
+      if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
+      while ((pitch + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
+      geo.pitch = pitch;
+      geo.span = span;
+      geo.spans = uint32_t((pitch + span + span - 1) / span);
+      out_total = 0;
+      for (milzma_unit& u : units) {
+        u.out_off = out_total;
+        out_total += pitch;
+      }
+    }
+  }
   if (nu) {
     // Decoding ahead is an optimisation: if its memory cannot be had (or anything else goes wrong here) the walk below
     // decodes every block on demand and each file still gets the reference's verdict.
@@ -2046,28 +2443,137 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
           !dev_reserve(ctx, ctx->out, out_total + 512) || !dev_reserve(ctx, ctx->crc, parts_bytes))
         return false;
       uint8_t* hin = static_cast<uint8_t*>(ctx->pin_in.p);
-      {
-        // eight groups of files: the gather of one group overlaps the transfer of the one before
-        std::vector<uint32_t> pf;
-        for (uint32_t i = 0; i < n; i++)
-          if (planned[i]) pf.push_back(i);
-        const size_t groups = std::min<size_t>(8, pf.size());
-        std::vector<size_t> first(groups + 1), bounds(groups + 1);
-        for (size_t g = 0; g <= groups; g++) {
-          first[g] = pf.size() * g / groups;
-          bounds[g] = g == groups ? in_total : file_in_off[pf[first[g]]];
-        }
-        if (!staged_h2d(ctx, ctx->in.p, hin, bounds, [&](size_t g) {
-              parallel_for(first[g + 1] - first[g], [&](size_t k0) {
-                const uint32_t i = pf[first[g] + k0];
-                memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
-              });
-            }))
-          return false;
+      // the planned files, in groups: the gather of one group overlaps the transfer of the one before
+      std::vector<uint32_t> pf;
+      for (uint32_t i = 0; i < n; i++)
+        if (planned[i]) pf.push_back(i);
+      const size_t groups = std::min<size_t>(geo.spans ? 16 : 8, pf.size());
+      std::vector<size_t> first(groups + 1), bounds(groups + 1);
+      for (size_t g = 0; g <= groups; g++) {
+        first[g] = pf.size() * g / groups;
+        bounds[g] = g == groups ? in_total : file_in_off[pf[first[g]]];
       }
+      const auto fill = [&](size_t g) {
+        parallel_for(first[g + 1] - first[g], [&](size_t k0) {
+          const uint32_t i = pf[first[g] + k0];
+          memcpy(hin + file_in_off[i], ins[i], in_lens[i]);
+        });
+      };
       hipStream_t ws = work_stream(ctx);
-      if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) return false;
-      // (milzma_decode_units leaves the units and the final results in ctx->units / ctx->results)
+      void* host_dev = nullptr;
+      const bool stream_it = geo.spans && hipHostGetDevicePointer(&host_dev, ctx->pin_out.p, 0) == hipSuccess && ensure_progress(ctx);
+      // The input goes up whole before the launch (gather of one group of files under the transfer of the one before).  The two-part
+      // form the .lzma batches use (upload_leads / upload_rest) is there for MILZMA_TWO_PART=1: measured on the 16-core GPU boxes the
+      // host's gather (~23 GB/s) is what both forms wait for, and with four blocks per file the second part came too late for the
+      // decoders (profiles/r04_batch_api.txt).
+      static const bool two_part = getenv("MILZMA_TWO_PART") && !strcmp(getenv("MILZMA_TWO_PART"), "1");
+      if (!stream_it) (void)hipGetLastError();
+      if (!(stream_it && two_part) && !staged_h2d(ctx, ctx->in.p, hin, bounds, fill)) return false;
+      if (stream_it) {
+        // the files' result buffers page-locked from the pool, every block written to its place by the waves themselves (kernels.h:
+        // host_ptrs); without page-locked memory: ordinary buffers, filled from the staging buffer by a host thread
+        std::atomic<int> alloc_failed{0};
+        bool direct = pinned_results_wanted();
+        if (direct) {
+          parallel_for(n, [&](size_t i) {
+            if (planned[i] && !filebuf[i].reserve_pinned(file_out_hint[i] + 512)) alloc_failed = 1;
+          });
+          if (alloc_failed) {
+            for (OutBuf& b : filebuf) {
+              milzma_free(b.p);
+              b.p = nullptr;
+              b.cap = 0;
+            }
+            alloc_failed = 0;
+            direct = false;
+          }
+        }
+        if (!direct)
+          parallel_for(n, [&](size_t i) {
+            if (planned[i] && !filebuf[i].reserve(std::max<size_t>(file_out_hint[i], 1))) alloc_failed = 1;
+          });
+        if (direct && !alloc_failed) {
+          std::vector<uint64_t> ptrs(size_t(nu) * 2);   // (a block never writes beyond the size the Index gives it: the next block's place)
+          for (uint32_t k = 0; k < nu; k++) {
+            ptrs[2 * size_t(k)] = uint64_t(reinterpret_cast<uintptr_t>(filebuf[refs[k].file].p + refs[k].blk_off));
+            ptrs[2 * size_t(k) + 1] = refs[k].unpacked;
+          }
+          if (!upload_host_ptrs(ctx, ptrs, ws)) alloc_failed = 1;
+        }
+        // the input in two parts (upload_leads / upload_rest): every block's first bytes before the launch, the files while it runs
+        trace_mark(ctx, "streamed: leads");
+        if (two_part && (alloc_failed || !upload_leads(ctx, units, [&](size_t k) { return ins[refs[k].file] + refs[k].data_off; }, ws))) {
+          if (!staged_h2d(ctx, ctx->in.p, hin, bounds, fill)) return false;
+          alloc_failed = 1;   // (falls through to the classic decode below)
+        }
+        if (!alloc_failed) {
+          __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 0u, __ATOMIC_RELEASE);
+          ctx->stream_span = uint32_t(geo.span);
+          ctx->stream_spans = geo.spans;
+          ctx->stream_host = static_cast<uint8_t*>(host_dev);
+          ctx->stream_ptrs = direct ? static_cast<const uint64_t*>(ctx->hostptrs.p) : nullptr;
+          ctx->stream_in_host = two_part;
+          trace_mark(ctx, "streamed: launch");
+          const bool launched = milzma_decode_units_async_impl(ctx, units.data(), nu, ctx->in.p, ctx->out.p, ws, 0, nullptr) == MILZMA_OK;
+          ctx->stream_span = ctx->stream_spans = 0;
+          ctx->stream_host = nullptr;
+          ctx->stream_ptrs = nullptr;
+          ctx->stream_in_host = false;
+          const bool rest = !two_part || upload_rest(ctx, hin, bounds, fill);
+          trace_mark(ctx, "streamed: input complete");
+          if (!rest) {
+            if (launched) (void)milzma_decode_units_wait_impl(ctx, res.data());
+            return false;
+          }
+          if (!launched) return false;
+          if (ctx->stream_active) {
+            std::atomic<bool> kernel_done{false};
+            const uint8_t* pout = static_cast<const uint8_t*>(ctx->pin_out.p);
+            std::thread consumer([&] {
+              if (direct) return;   // (the waves put the blocks in place themselves)
+              for (uint32_t sp = 0; sp < geo.spans; sp++) {
+                while (__atomic_load_n(&ctx->progress[sp], __ATOMIC_ACQUIRE) < nu && !kernel_done.load(std::memory_order_acquire))
+                  std::this_thread::sleep_for(std::chrono::microseconds(50));
+                parallel_for(nu, [&](size_t k) {
+                  const size_t phase = (k & 15u) * (geo.span >> 4), len = refs[k].unpacked;
+                  const size_t lo = sp * geo.span > phase ? sp * geo.span - phase : 0, hi = std::min(len, (sp + 1) * geo.span - phase);
+                  if (lo < hi) memcpy(filebuf[refs[k].file].p + refs[k].blk_off + lo, pout + size_t(units[k].out_off) + lo, hi - lo);
+                });
+              }
+            });
+            const int wr = milzma_decode_units_wait_impl(ctx, res.data());
+            kernel_done.store(true, std::memory_order_release);
+            consumer.join();
+            trace_mark(ctx, "streamed decode + placement: done");
+            if (wr != MILZMA_OK) return false;
+            streamed_done = true;
+            streamed_direct = direct;
+            if (direct)   // (the waves wrote no more than the Index's size to a block's place: the rare longer block is fetched whole)
+              for (uint32_t k = 0; k < nu; k++)
+                if (res[k].status == MILZMA_ST_OK && res[k].out_len > refs[k].unpacked && res[k].out_len <= units[k].out_cap) {
+                  std::vector<uint8_t>& v = longer[k];
+                  v.resize(size_t(res[k].out_len));
+                  if (!hip_ok(ctx, hipMemcpy(v.data(), static_cast<const uint8_t*>(ctx->out.p) + units[k].out_off, v.size(), hipMemcpyDeviceToHost),
+                              "D2H block"))
+                    return false;
+                }
+          } else if (milzma_decode_units_wait_impl(ctx, res.data()) != MILZMA_OK) {
+            return false;
+          }
+        } else if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) {
+          return false;
+        }
+      } else if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) {
+        return false;
+      }
+      // (the decode leaves the units and the final results in ctx->units / ctx->results)
+      if (streamed_done)   // the output is on the host already: only the blocks' CRC parts are still to come
+        return hip_ok(ctx,
+                      launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
+                                       static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, ws),
+                      "crc kernel launch") &&
+               hip_ok(ctx, hipMemcpyAsync(ctx->pin_small.p, ctx->crc.p, parts_bytes, hipMemcpyDeviceToHost, ws), "D2H crc parts") &&
+               hip_ok(ctx, hipStreamSynchronize(ws), "hipStreamSynchronize");
       return hip_ok(ctx,
                     launch_crc_units(static_cast<const milzma_unit*>(ctx->units.p), nu, static_cast<const uint8_t*>(ctx->out.p),
                                      static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, ws),
@@ -2087,6 +2593,8 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   //    (one GPU user at a time).
   std::vector<std::unordered_map<size_t, size_t>> by_off(n);
   for (size_t k = 0; k < refs.size(); k++) by_off[refs[k].file][refs[k].data_off] = k;
+  std::vector<const uint8_t*> fb_base(n, nullptr);   // (the walks take the buffers over: their addresses, for the payloads inside them)
+  for (uint32_t i = 0; i < n; i++) fb_base[i] = filebuf[i].p;
   const PayloadFn live_unlocked = live_decoder(ctx);
   const PayloadFn live = [&](const uint8_t* in, size_t in_len, size_t cap_hint, Payload* p) {
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -2106,9 +2614,19 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
           const size_t k = it->second;
           const milzma_result& r = res[k];
           if (r.status == MILZMA_ST_OK && r.in_consumed == units[k].in_len && !(r.chunks & 0x80000000u) &&
-              r.out_len <= units[k].out_cap && d2h.wait_until(size_t(units[k].out_off + r.out_len))) {
+              r.out_len <= units[k].out_cap && (streamed_done || d2h.wait_until(size_t(units[k].out_off + r.out_len)))) {
             p->res = r;
-            p->data = hout + units[k].out_off;
+            // streamed: the block sits at its place in the file's buffer (and, unless the waves wrote it there themselves, in the
+            // staging buffer too); classic: in the staging buffer
+            p->data = streamed_done ? fb_base[i] + refs[k].blk_off : hout + units[k].out_off;
+            if (streamed_done && r.out_len == refs[k].unpacked) p->prefilled_at = refs[k].blk_off;
+            if (streamed_direct && r.out_len > refs[k].unpacked) {
+              const auto lit = longer.find(k);
+              if (lit == longer.end()) return live(in, in_len, cap_hint, p);
+              p->data = lit->second.data();
+            } else if (streamed_done && !streamed_direct && r.out_len > refs[k].unpacked) {
+              p->data = hout + units[k].out_off;   // (whole in the staging buffer)
+            }
             crc_fold(parts + k * kCrcPartsBytes, r.out_len, &p->crc32, &p->crc64);
             p->has_crc = true;
             return true;
@@ -2117,7 +2635,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
       }
       return live(in, in_len, cap_hint, p);
     };
-    xz_walk(ctx, ins[i], in_lens[i], fn, &outs[i], file_out_hint[i]);
+    xz_walk(ctx, ins[i], in_lens[i], fn, &outs[i], file_out_hint[i], streamed_done ? &filebuf[i] : nullptr);
   });
   return MILZMA_OK;
 }
@@ -2521,6 +3039,10 @@ extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results)
 struct milzma_multi {
   std::vector<milzma_ctx*> ctx;
   std::string err;
+  // milzma_multi_decode_units_rooted: staging on the root device for what travels to / from the other devices, and how long it took
+  DevBuf stage_in, stage_out;
+  int stage_device = -1;
+  float scatter_ms = 0.f, decode_ms = 0.f, gather_ms = 0.f;
 };
 
 namespace {
@@ -2710,6 +3232,10 @@ extern "C" int milzma_multi_create(uint64_t device_mask, milzma_multi** out) {
 
 extern "C" void milzma_multi_destroy(milzma_multi* m) {
   if (!m) return;
+  if (m->stage_device >= 0 && hipSetDevice(m->stage_device) == hipSuccess) {
+    dev_release(m->stage_in);
+    dev_release(m->stage_out);
+  }
   for (milzma_ctx* c : m->ctx) milzma_destroy(c);
   delete m;
 }
@@ -2774,6 +3300,157 @@ extern "C" int milzma_multi_decode_units(milzma_multi* m, const milzma_unit* uni
   } catch (const std::exception& e) {
     return multi_fail(m, std::string("host exception: ") + e.what());
   }
+}
+
+// One ingest point (north_star: "input scatter and output gather over xGMI"): the whole batch lives in the memory of ONE device of
+// the handle -- `root` -- and comes back there.  The units are partitioned by compressed bytes like everywhere else; the root's own
+// share is decoded in place; every other device's share is packed on the root (one move kernel), crosses to that device with ONE
+// device-to-device copy (hipMemcpyPeer: the direct xGMI link between the two GPUs where peer access exists), is decoded there, and
+// its output crosses back the same way and is put in place by one more move kernel.  All devices work concurrently, each on its own
+// host thread; nothing passes through host memory and there is no collective (each device talks to the root only).
+extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, const milzma_unit* units, uint32_t n, const void* d_in,
+                                                void* d_out, milzma_result* results) {
+  if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  try {
+    using clk = std::chrono::steady_clock;
+    const auto ms_since = [](clk::time_point t0) { return std::chrono::duration<float, std::milli>(clk::now() - t0).count(); };
+    m->scatter_ms = m->decode_ms = m->gather_ms = 0.f;
+    if (n == 0) return MILZMA_OK;
+    const uint32_t nd = uint32_t(m->ctx.size());
+    if (!units || !d_in || !d_out || !results) return multi_fail(m, "null argument");
+    if (root >= nd) return multi_fail(m, "root: device index out of range");
+    milzma_ctx* rc = m->ctx[root];
+    std::vector<uint64_t> w(n);
+    for (uint32_t i = 0; i < n; i++) w[i] = units[i].in_len + 1;
+    std::vector<uint32_t> part(n);
+    partition_impl(w.data(), nullptr, n, nd, part.data());
+    // (the planner numbers parts 0..nd-1 by load: which part the root keeps does not matter, every part is about the same size)
+    std::vector<std::vector<uint32_t>> share(nd);
+    for (uint32_t i = 0; i < n; i++) share[part[i]].push_back(i);
+    // packed layouts of the shares that travel
+    std::vector<std::vector<milzma_unit>> sub(nd);
+    std::vector<size_t> in_base(nd, 0), out_base(nd, 0), in_bytes(nd, 0), out_bytes(nd, 0);
+    size_t in_total = 0, out_total = 0;
+    std::vector<uint64_t> so, dof, ln;
+    for (uint32_t k = 0; k < nd; k++) {
+      if (k == root) continue;
+      in_base[k] = in_total;
+      out_base[k] = out_total;
+      sub[k].resize(share[k].size());
+      size_t io = 0, oo = 0;
+      for (size_t j = 0; j < share[k].size(); j++) {
+        const milzma_unit& u = units[share[k][j]];
+        sub[k][j] = u;
+        sub[k][j].in_off = io;
+        sub[k][j].out_off = oo;
+        so.push_back(u.in_off);
+        dof.push_back(in_total + io);
+        ln.push_back(u.in_len);
+        io += round_up(size_t(u.in_len), 256);
+        oo += round_up(size_t(u.out_cap), 256);
+      }
+      in_bytes[k] = io;
+      out_bytes[k] = oo;
+      in_total += io;
+      out_total += oo;
+    }
+    if (!hip_ok(rc, hipSetDevice(rc->device), "hipSetDevice")) return multi_fail(m, rc->err);
+    if (m->stage_device != rc->device) {  // (the staging follows the root)
+      if (m->stage_device >= 0 && hipSetDevice(m->stage_device) == hipSuccess) {
+        dev_release(m->stage_in);
+        dev_release(m->stage_out);
+      }
+      (void)hipSetDevice(rc->device);
+      m->stage_device = rc->device;
+    }
+    if (!dev_reserve(rc, m->stage_in, in_total + 512) || !dev_reserve(rc, m->stage_out, out_total + 512)) return multi_fail(m, rc->err);
+    // 1. scatter, root side: pack what leaves
+    const auto t_scatter = clk::now();
+    if (!so.empty() && move_units_impl(rc, uint32_t(so.size()), d_in, so.data(), m->stage_in.p, dof.data(), ln.data(), work_stream(rc)) != MILZMA_OK)
+      return multi_fail(m, rc->err);
+    // 2. every device: its share in, decode, its output back
+    std::vector<int> rcode(nd, MILZMA_OK);
+    std::vector<float> t_in(nd, 0.f), t_dec(nd, 0.f), t_out(nd, 0.f);
+    std::vector<std::vector<milzma_result>> res(nd);
+    per_device(
+        nd,
+        [&](size_t k) {
+          milzma_ctx* c = m->ctx[k];
+          c->last_ms = 0.f;
+          c->last_launches = 0;
+          if (share[k].empty()) return;
+          res[k].resize(share[k].size());
+          const auto bad = [&]() { rcode[k] = MILZMA_INFRA_ERROR; };
+          if (k == root) {
+            std::vector<milzma_unit> own(share[k].size());
+            for (size_t j = 0; j < own.size(); j++) own[j] = units[share[k][j]];
+            const auto t0 = clk::now();
+            if (milzma_decode_units(c, own.data(), uint32_t(own.size()), d_in, d_out, res[k].data(), work_stream(c)) != MILZMA_OK) return bad();
+            t_dec[k] = ms_since(t0);
+            return;
+          }
+          if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice") || !dev_reserve(c, c->in, in_bytes[k] + 512) ||
+              !dev_reserve(c, c->out, out_bytes[k] + 512))
+            return bad();
+          auto t0 = clk::now();
+          if (!hip_ok(c, hipMemcpyPeer(c->in.p, c->device, static_cast<const uint8_t*>(m->stage_in.p) + in_base[k], rc->device, in_bytes[k]),
+                      "device-to-device scatter"))
+            return bad();
+          t_in[k] = ms_since(t0);
+          t0 = clk::now();
+          if (milzma_decode_units(c, sub[k].data(), uint32_t(sub[k].size()), c->in.p, c->out.p, res[k].data(), work_stream(c)) != MILZMA_OK)
+            return bad();
+          t_dec[k] = ms_since(t0);
+          t0 = clk::now();
+          if (!hip_ok(c, hipMemcpyPeer(static_cast<uint8_t*>(m->stage_out.p) + out_base[k], rc->device, c->out.p, c->device, out_bytes[k]),
+                      "device-to-device gather"))
+            return bad();
+          t_out[k] = ms_since(t0);
+        },
+        [&](size_t k, const char* what) {
+          rcode[k] = MILZMA_INFRA_ERROR;
+          m->ctx[k]->err = std::string("host exception: ") + what;
+        });
+    for (uint32_t k = 0; k < nd; k++)
+      if (rcode[k] != MILZMA_OK) return multi_fail(m, "device " + std::to_string(m->ctx[k]->device) + ": " + m->ctx[k]->err);
+    // 3. gather, root side: every travelled output into its place
+    const auto t_gather = clk::now();
+    so.clear();
+    dof.clear();
+    ln.clear();
+    for (uint32_t k = 0; k < nd; k++)
+      for (size_t j = 0; j < share[k].size(); j++) {
+        const uint32_t i = share[k][j];
+        results[i] = res[k][j];
+        if (k == root) continue;
+        so.push_back(out_base[k] + sub[k][j].out_off);
+        dof.push_back(units[i].out_off);
+        ln.push_back(std::min<uint64_t>(res[k][j].out_len, units[i].out_cap));
+      }
+    if (!hip_ok(rc, hipSetDevice(rc->device), "hipSetDevice") ||
+        (!so.empty() && move_units_impl(rc, uint32_t(so.size()), m->stage_out.p, so.data(), d_out, dof.data(), ln.data(), work_stream(rc)) != MILZMA_OK))
+      return multi_fail(m, rc->err);
+    const float place_ms = ms_since(t_gather);
+    float in_max = 0.f, out_max = 0.f, dec_max = 0.f;
+    for (uint32_t k = 0; k < nd; k++) {
+      in_max = std::max(in_max, t_in[k]);
+      out_max = std::max(out_max, t_out[k]);
+      dec_max = std::max(dec_max, t_dec[k]);
+    }
+    (void)t_scatter;
+    m->scatter_ms = in_max;       // the slowest device's copy in (the packing on the root runs before the threads start: included below)
+    m->decode_ms = dec_max;
+    m->gather_ms = out_max + place_ms;
+    return MILZMA_OK;
+  } catch (const std::exception& e) {
+    return multi_fail(m, std::string("host exception: ") + e.what());
+  }
+}
+
+extern "C" void milzma_multi_last_transfer_ms(const milzma_multi* m, float* scatter_ms, float* decode_ms, float* gather_ms) {
+  if (scatter_ms) *scatter_ms = m ? m->scatter_ms : 0.f;
+  if (decode_ms) *decode_ms = m ? m->decode_ms : 0.f;
+  if (gather_ms) *gather_ms = m ? m->gather_ms : 0.f;
 }
 
 extern "C" int milzma_multi_decode_units_host(milzma_multi* m, const milzma_unit* units, uint32_t n, const void* h_in, size_t in_bytes,

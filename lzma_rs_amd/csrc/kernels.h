@@ -39,7 +39,15 @@ size_t slice_ctx_bytes();  // per unit, the same for both instantiations
 size_t slice_queue_bytes(uint32_t cap);
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow);
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t span_bytes = 0,
+                              uint32_t n_spans = 0, uint32_t* progress = nullptr, uint8_t* host_out = nullptr, uint32_t* in_ready = nullptr,
+                              const uint64_t* host_ptrs = nullptr);
+// host_ptrs (device array, one entry per unit of the batch, or null): the unit's own destination in host memory (0: none)
+// in_ready (streamed launches that read their input from host memory): a word in such memory the host sets once every unit's input
+// is complete; before that only the first stream_lead_bytes(in_len) bytes of each unit are guaranteed
+uint32_t stream_lead_bytes(uint32_t in_len);
+// Streamed launches: the waves write their output to host_out (page-locked host memory the device can reach, same offsets as d_out)
+// span by span; progress: n_spans counters in such memory, counter s = units whose span s has arrived (see SliceQueue)
 // grow: growable output (milzma_decode_units_ex) -- a unit that runs out of room is parked in d_ctxmem with status OUT_FULL /
 // err_a = MILZMA_PARKED; d_order entries with bit 31 set resume such a unit (parked by an earlier launch with the same d_ctxmem)
 

@@ -106,7 +106,8 @@ size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap)
 
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow) {
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t span_bytes,
+                              uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready, const uint64_t* host_ptrs) {
   if (n == 0) return hipSuccess;
   auto* q = static_cast<SliceQueue*>(d_queue);
   auto* ring = reinterpret_cast<uint32_t*>(q + 1);
@@ -116,7 +117,7 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
   const uint32_t waves = std::min(n, resident);
   hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
                      d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem), grow ? 1u : 0u,
-                     uint32_t(slice_ctx_bytes() / sizeof(uint32_t)));
+                     uint32_t(slice_ctx_bytes() / sizeof(uint32_t)), progress ? span_bytes : 0u, n_spans, progress, host_out, progress ? in_ready : nullptr, progress ? host_ptrs : nullptr);
   if (lc4)
     hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<16>, dim3(waves), dim3(kWave), lds_pad, stream, q);
   else
@@ -150,6 +151,8 @@ hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_
   hipLaunchKernelGGL(move_units_kernel, dim3(n), dim3(256), 0, stream, d_src, d_dst, d_offs, n);
   return hipGetLastError();
 }
+
+uint32_t stream_lead_bytes(uint32_t in_len) { return stream_lead(in_len); }
 
 hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results,
                             void* d_parts, hipStream_t stream) {
