@@ -1315,6 +1315,23 @@ struct StreamedSlot {
   }
 };
 
+// streamed launches are for batches it pays for: at least this many units and output bytes (MILZMA_STREAM_MIN="units,bytes": tests
+// send small batches down the path)
+void stream_minimum(size_t* units, size_t* bytes) {
+  static size_t mu = 256, mb = size_t(256) << 20;
+  static const bool init = [] {
+    if (const char* e = getenv("MILZMA_STREAM_MIN")) {
+      char* end = nullptr;
+      mu = size_t(strtoull(e, &end, 0));
+      if (end && *end == ',') mb = size_t(strtoull(end + 1, nullptr, 0));
+    }
+    return true;
+  }();
+  (void)init;
+  *units = mu;
+  *bytes = mb;
+}
+
 bool pinned_results_wanted() {
   static const bool off = getenv("MILZMA_PINNED_OUT") && !strcmp(getenv("MILZMA_PINNED_OUT"), "0");
   return !off;
@@ -1430,28 +1447,33 @@ extern "C" int milzma_lzma_read_header(const uint8_t* in, size_t in_len, const m
   if (!out) out = &scratch;
   out_reset(out);
   Cursor c{in, 0, in_len};
+  // (on failure the reader stands where the reference's stands: behind the bytes its read calls took -- all there were, for a short one)
+  const auto fail_at = [&](int kind, const char* fmt, auto... a) {
+    out->in_consumed = c.pos;
+    return out_fail(out, kind, fmt, a...);
+  };
   uint8_t props;
-  if (!c.u8(&props)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+  if (!c.u8(&props)) return fail_at(MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
   uint32_t pb = props;
-  if (pb >= 225) return out_fail(out, MILZMA_LZMA_ERROR, "LZMA header invalid properties: %u must be < 225", pb);
+  if (pb >= 225) return fail_at(MILZMA_LZMA_ERROR, "LZMA header invalid properties: %u must be < 225", pb);
   const uint32_t lc = pb % 9;
   pb /= 9;
   const uint32_t lp = pb % 5;
   pb /= 5;
   uint32_t dict;
-  if (!c.u32le(&dict)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+  if (!c.u32le(&dict)) return fail_at(MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
   if (dict < 0x1000) dict = 0x1000;
   uint64_t unpacked = MILZMA_SIZE_UNKNOWN;
   switch (opt->unpacked_size_mode) {
     case MILZMA_READ_FROM_HEADER: {
       uint64_t v;
-      if (!c.u64le(&v)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+      if (!c.u64le(&v)) return fail_at(MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
       unpacked = v;  // 0xFFFF_FFFF_FFFF_FFFF == marker mode == MILZMA_SIZE_UNKNOWN
       break;
     }
     case MILZMA_READ_HEADER_BUT_USE_PROVIDED: {
       uint64_t v;
-      if (!c.u64le(&v)) return out_fail(out, MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
+      if (!c.u64le(&v)) return fail_at(MILZMA_HEADER_TOO_SHORT, "%s", kEofMsg);
       unpacked = opt->provided_is_some ? opt->provided : MILZMA_SIZE_UNKNOWN;
       break;
     }
@@ -1583,7 +1605,9 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   {
     static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
     size_t max_cap = 0;
-    bool all_fast = ctx->use_fast && !off && units.size() >= 256 && out_total >= (size_t(256) << 20);
+    size_t min_units, min_bytes;
+    stream_minimum(&min_units, &min_bytes);
+    bool all_fast = ctx->use_fast && !off && units.size() >= min_units && out_total >= min_bytes;
     for (const milzma_unit& u : units) {
       max_cap = std::max(max_cap, size_t(u.out_cap));
       all_fast = all_fast && classify(ctx, u) == kFast;
@@ -2101,6 +2125,9 @@ int read_block(milzma_ctx* ctx, Cursor& c, size_t block_start, OutBuf& output, i
     const size_t hint = (i == 0 && bh.has_unpacked) ? size_t(std::min<uint64_t>(bh.unpacked, MILZMA_MAX_UNIT_BYTES)) : 0;
     if (!decode(src, src_len, hint, &next)) return infra(ctx, o);
     if (next.res.status != MILZMA_ST_OK) {
+      // (the LZMA2 decoder read from the file's reader: it stands where the payload's decode stopped -- round 4: was left at the
+      //  payload's first byte, nothing compared the position of failed decodes)
+      if (i == 0) c.pos += size_t(std::min<uint64_t>(next.res.in_consumed, c.end - c.pos));
       o->kind = milzma_result_message(&next.res, MILZMA_KIND_LZMA2, o->msg, sizeof o->msg);
       return o->kind;
     }
@@ -2417,7 +2444,9 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
     size_t max_cap = 0;
     for (const milzma_unit& u : units) max_cap = std::max(max_cap, size_t(u.out_cap));
     const size_t pitch = round_up(max_cap, 256);
-    if (ctx->use_fast && !off && nu >= 256 && out_total >= (size_t(256) << 20) && pitch * nu <= out_total + out_total / 4 &&
+    size_t min_units, min_bytes;
+    stream_minimum(&min_units, &min_bytes);
+    if (ctx->use_fast && !off && nu >= min_units && out_total >= min_bytes && pitch * nu <= out_total + out_total / 4 &&
         in_total + pitch * nu <= budget && streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
       if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));

@@ -42,7 +42,9 @@ def same(dec, ref, check_consumed=True):
     """dec: lzma_rs_amd.Decoded, ref: oracle_py.OracleResult"""
     assert (dec.kind, dec.msg) == (ref.kind, ref.msg), (dec, ref)
     assert dec.data == ref.out, (len(dec.data), len(ref.out))
-    if check_consumed and ref.ok:
+    # the reader's position, on success AND on error (round 4: a truncated stream used to leave it one byte beyond the end of the
+    # input -- nothing compared it for failed decodes)
+    if check_consumed:
         assert dec.in_consumed == ref.in_consumed, (dec, ref)
 
 
@@ -1013,3 +1015,49 @@ def test_thousands_of_wrong_guesses_are_resumed_not_redecoded(ctx):
     raw = lzma.compress(plains[7] * 4, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}])
     d = ctx.lzma2(raw)
     assert d.ok and d.data == plains[7] * 4
+
+
+# ---- streamed launches: the whole-file batch calls whose waves write their output to the caller's buffers themselves -------------
+
+@pytest.mark.parametrize("pinned", ["1", "0"])
+def test_streamed_whole_file_batches_match_the_oracle(monkeypatch, pinned):
+    """The streamed form of the batch calls (one time-sliced launch, output spans written to the host by the waves --
+    into page-locked result buffers, or with MILZMA_PINNED_OUT=0 into a staging buffer a host thread copies from --, the .lzma input
+    in two parts) is the default only for large uniform batches; MILZMA_STREAM_MIN sends small ones down the same path: equal-sized
+    streams of every class, unknown sizes (parked and resumed afterwards), truncated and damaged ones, LZMA2 streams and .xz files
+    (good, with a lying Index, the 34 malformed ones) must come out exactly as the oracle says."""
+    import test_xz_literals as X
+    monkeypatch.setenv("MILZMA_STREAM_MIN", "2,1")
+    monkeypatch.setenv("MILZMA_SPAN", "65536")
+    monkeypatch.setenv("MILZMA_PINNED_OUT", pinned)
+    rng = random.Random(8)
+    c = M.Context(0)
+    try:
+        for known in (True, False):
+            plains = [W.make_plain(["text", "random", "repeat", "text"][i % 4], 300_000, seed=600 + i) for i in range(40)]
+            comps = [W.compress_alone(p, dict_size=1 << 16, known_size=known) for p in plains]
+            comps[7] = comps[7][:len(comps[7]) // 2]
+            comps[11] = comps[11][:2000] + bytes([comps[11][2000] ^ 0x40]) + comps[11][2001:]
+            for comp, d in zip(comps, c.lzma_batch(comps)):
+                r = orc.lzma_decompress(comp)
+                assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
+        raws = [lzma.compress(W.make_plain("text", 250_000, seed=700 + i) + os.urandom(70_000), format=lzma.FORMAT_RAW,
+                              filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}]) for i in range(12)]
+        for comp, d in zip(raws, c.lzma2_batch(raws)):
+            r = orc.lzma2_decompress(comp)
+            assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
+        # .xz: multi-block files of one block size; a file whose Index understates a block; the malformed ones
+        blocks = [W.make_plain("text", 200_000, seed=800 + i) for i in range(24)]
+        xzs = [W.compress_xz_blocks(b"".join(blocks[3 * i:3 * i + 3]), block_size=200_000, check="crc64") for i in range(8)]
+        # (the Index understates block 1 by 8 bytes: the unit still fits its slice and ends OK, but longer than its place in the file's
+        #  buffer -- the streamed path must deliver the block's TRUE bytes before the walk reports the Index; and by 4000: OUT_FULL)
+        for lie in (8, 4000):
+            bl = [X.block(blocks[j], check=4) for j in range(3)]
+            idx = X.index([(bl[0][1], bl[0][2]), (bl[1][1], bl[1][2] - lie), (bl[2][1], bl[2][2])])
+            xzs.append(X.xz_file(check=4, blocks=bl, idx=idx))
+        xzs += [data for _name, (data, _k, _m) in sorted(X.CASES.items())]
+        for comp, d in zip(xzs, c.xz_batch(xzs)):
+            r = orc.xz_decompress(comp)
+            assert (d.kind, d.msg, d.data) == (r.kind, r.msg, r.out)
+    finally:
+        c.close()

@@ -71,6 +71,14 @@ def test_read_header_matches_oracle():
     for props in range(225):
         u, _ = M.lzma_read_header(bytes([props]) + hello[1:])
         assert u.lc + 9 * (u.lp + 5 * u.pb) == props
+    # where the reader stands after a header that fails: behind what the reference's read calls took (round 4: was 0)
+    L = M.lib()
+    for data in (b"\xff" + hello[1:], hello[:0], hello[:1], hello[:4], hello[:5], hello[:12]):
+        u, hl, out = M.Unit(), ctypes.c_size_t(), M._COutput()
+        p, n, keep = M._as_buffer(data)
+        kind = L.milzma_lzma_read_header(p, n, None, ctypes.byref(u), ctypes.byref(hl), ctypes.byref(out))
+        ref = orc.lzma_decompress(data)
+        assert (kind, out.msg.decode(), out.in_consumed) == (ref.kind, ref.msg, ref.in_consumed)
 
 
 def test_crc_matches_oracle():

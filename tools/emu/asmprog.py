@@ -415,7 +415,9 @@ class AsmLoop:
                 status = name
         in_consumed = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF   # (an end-aligned last window may start "before" 0)
         if status == ST_INPUT_EOF:
-            in_consumed = in_len
+            # the failing normalisation had already advanced its byte offset: AsmDecoder::process takes that one back
+            in_consumed = (in_consumed - 1) & 0xFFFFFFFF
+            assert in_consumed == in_len, (in_consumed, in_len)
         return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,
                     executed=executed, yields=yields)
 
