@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 CUS, CLOCK_GHZ = 256, 2.4
+PROFILE_ROUND = "r04"   # profiles/<round>_pmc_<config>.json and _instruction_mix_<config>.json are read only if their kernel hash is this build's
 SALU_IPC, CHAIN_IPC = 1.72, 1.71  # measured issue ceilings per CU per cycle at 16 waves/CU (profiles/r02_chain_latency.txt)
 
 PROPS = (3, 0, 2)  # lc, lp, pb of the generated .lzma streams (--props; the forked compression workers inherit it)
@@ -251,7 +252,7 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash):
     """The decode kernel against the measured instruction-issue ceiling of its own decision chain (what binds it), from the exact
     executed-instruction mix of this workload (tools/emu/profile.py over 16 streams); None if the recorded mix belongs to
     another kernel source or workload."""
-    mix_path = os.path.join(ROOT, "profiles", "r03_instruction_mix_%s.json" % config)
+    mix_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_instruction_mix_%s.json" % config)
     if kind != "text" or not os.path.exists(mix_path):
         return None
     with open(mix_path) as f:
@@ -276,10 +277,10 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash):
 
 
 def pmc_traffic(config, khash):
-    """HBM bytes per launch from the recorded PMC passes (profiles/r03_pmc_<config>.json): of this kernel source, or of an earlier one the
-    record explicitly names this source compatible with (`also_valid_for`: the loop's memory instructions unchanged; the reason is in
-    the record and repeated in the line as `traffic_recorded_on`).  Returns (bytes or None, note or None)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % config)
+    """HBM bytes per launch from the recorded PMC passes (profiles/<round>_pmc_<config>.json) -- only if they were taken with exactly
+    this kernel source (the record's kernel_source_sha256); there is no attestation for other sources any more (round 3's
+    `also_valid_for` is gone).  Returns (bytes or None, None)."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_%s.json" % config)
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -287,9 +288,6 @@ def pmc_traffic(config, khash):
     val = pmc.get("derived", {}).get("hbm_bytes_per_launch")
     if pmc.get("kernel_source_sha256") == khash:
         return val, None
-    ok = pmc.get("also_valid_for", {})
-    if khash in ok:
-        return val, "PMC passes taken on kernel source %s; valid for %s because: %s" % (pmc.get("kernel_source_sha256"), khash, ok[khash])
     return None, None
 
 
@@ -943,7 +941,7 @@ def main():
     k_ms = statistics.median(kernel_ms)
     khash = kernel_source_hash()
     traffic, traffic_note = None, "no PMC pass recorded for this kernel source and workload"
-    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.config)
+    pmc_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_%s.json" % args.config)
     if os.path.exists(pmc_path) and args.kind == "text" and (n, size, dict_size) == (cfg["streams"], cfg["size"], cfg["dict"]):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -952,7 +950,7 @@ def main():
             traffic = t
             traffic_note = pmc["derived"]["traffic_note"] + ("  [" + recorded_on + "]" if recorded_on else "")
         else:
-            traffic_note = "profiles/r03_pmc_%s.json was taken with another kernel source (%s)" % (args.config, pmc.get("kernel_source_sha256"))
+            traffic_note = "profiles/%s_pmc_%s.json was taken with another kernel source (%s)" % (PROFILE_ROUND, args.config, pmc.get("kernel_source_sha256"))
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     scalar = issue_roofline(args.config, args.kind, out_bytes_rank, k_ms, khash)
@@ -993,6 +991,10 @@ def main():
                 "note": "serial range-decoder dependency chain and scalar issue bound this path, not HBM (DESIGN.md)",
             },
         }
+        if os.path.exists(pmc_path) and traffic is not None:   # (same passes: where a wave's cycles go, MI355X_MICROARCH.md's SQ counters)
+            shares = pmc.get("derived", {}).get("wave_cycle_shares")
+            if shares:
+                line["roofline"]["wave_cycle_shares"] = shares
         if scalar is not None:
             line["roofline_issue"] = scalar
         line["cpu_baseline"] = cpu_line

@@ -108,6 +108,7 @@ struct milzma_ctx {
   uint32_t budget_share = 1;
   // MILZMA_KERNEL=generic (A/B runs, tests) turns the lane-resident-model kernel off: everything runs in the generic one.
   bool use_fast = true;
+  bool fast_spill = true;    // MILZMA_SPILL=generic: lc + lp > 4 in the generic kernel (round 3's path) instead of the asm loop's HBM variant
   int slice_mode = 0;        // MILZMA_SLICE: 0 auto (launches that are not a whole number of chip-fulls), 1 always, -1 never ("0"),
                              // 2 always and every unit parked at every quantum even if nobody waits (tests)
   uint32_t slice_quantum = 128u << 10;  // MILZMA_QUANTUM: output bytes per turn of a time-sliced launch
@@ -318,6 +319,7 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   if (const char* k = getenv("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
   }
+  if (const char* k = getenv("MILZMA_SPILL")) ctx->fast_spill = strcmp(k, "generic") != 0;
   if (const char* k = getenv("MILZMA_SLICE")) ctx->slice_mode = !strcmp(k, "2") ? 2 : !strcmp(k, "1") ? 1 : !strcmp(k, "0") ? -1 : 0;
   if (const char* k = getenv("MILZMA_QUANTUM")) ctx->slice_quantum = std::max<uint32_t>(1u, uint32_t(strtoul(k, nullptr, 0)));
   if (const char* k = getenv("MILZMA_ORDER")) ctx->order_mode = !strcmp(k, "stride") ? 1 : !strcmp(k, "shuffle") ? 2 : 0;
@@ -540,7 +542,7 @@ LitClass classify(const milzma_ctx* ctx, const milzma_unit& u) {
   if (u.kind != MILZMA_KIND_RAW_LZMA) return ctx->use_fast ? kFast : kLitLds3;
   const uint32_t lclp = uint32_t(u.lc) + u.lp;
   if (ctx->use_fast && u.pb <= 4 && lclp <= 3) return kFast;
-  if (ctx->use_fast && u.pb <= 4 && lclp == 4) return kFastLc4;
+  if (ctx->use_fast && ctx->fast_spill && u.pb <= 4 && u.lc <= 8 && u.lp <= 4) return kFastSpill;   // lc + lp >= 4: the loop's HBM variant
   if (lclp <= 3) return kLitLds3;
   if (lclp <= 4) return kLitLds4;
   return kLitSpill;
@@ -572,6 +574,32 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   auto* d_results = static_cast<milzma_result*>(ctx->results.p);
   const uint32_t n = uint32_t(order.size());
   uint32_t step = n, spill_lclp = 0;
+  const bool is_fast = cls == kFast || cls == kFastSpill;
+  size_t slab_bytes = 0;
+  if (cls == kFastSpill) {
+    // The literal rows of every unit of the BATCH in one slab (indexed by unit, like the results: a unit keeps its rows across the
+    // turns of a time-sliced launch and across a park / resume), every probability 0x400 before the first launch.  Not to be had
+    // (half of the free memory at most): the generic kernel's spill class takes the units, chunk by chunk.
+    spill_lclp = 4;   // (at least what an LZMA2 unit can switch to)
+    for (uint32_t i : order) spill_lclp = std::max<uint32_t>(spill_lclp, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
+    spill_lclp = std::min<uint32_t>(spill_lclp, 12);
+    slab_bytes = spill_bytes_per_block(spill_lclp);
+    const size_t total = slab_bytes * ctx->pend_n;
+    size_t free_b = 0, total_b = 0;
+    const bool fits = slab_bytes <= 0xFFFFFFFFu && total <= kSpillSlabBytes * 4 &&
+                      (total <= ctx->scratch.cap || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total <= free_b / 2 + ctx->scratch.cap));
+    const std::string keep = ctx->err;
+    if (!fits || !dev_reserve(ctx, ctx->scratch, total)) {
+      ctx->err = keep;
+      if (resume) {
+        ctx->err = "no memory for the literal-row slab of parked units";
+        return false;
+      }
+      return launch_class(ctx, kLitSpill, order, order_base, d_in, d_out, stream);
+    }
+    if (!resume && !hip_ok(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(ctx->scratch.p), 0x0400, total / 2, stream), "slab memset"))
+      return false;
+  }
   if (cls == kLitSpill) {
     for (uint32_t i : order) spill_lclp = std::max<uint32_t>(spill_lclp, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
     spill_lclp = std::min<uint32_t>(spill_lclp, 12);
@@ -594,8 +622,8 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     // (20-34 KB per unit): if that cannot be had the ordinary launch does the job.
     bool sliced = false;
     uint32_t cap = 0;
-    if (cls == kFast || cls == kFastLc4) {
-      const uint32_t resident = fast_resident_blocks(cls == kFastLc4, ctx->lds_pad);
+    if (is_fast) {
+      const uint32_t resident = fast_resident_blocks(ctx->lds_pad);
       // (growable output is a feature of the time-sliced kernel: it is the one that can park a unit)
       const bool want_stream = ctx->stream_span != 0 && (ctx->stream_host != nullptr || ctx->stream_ptrs != nullptr) && m == ctx->pend_n && !resume;  // (the launch is the whole batch: the counters reach n)
       sliced = grow || want_stream || ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
@@ -632,15 +660,17 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
       }
     }
     const hipError_t le = sliced
-                              ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
+                              ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad,
                                                    static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
                                                    ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow, ctx->stream_span, ctx->stream_spans,
                                                    ctx->stream_active ? ctx->progress_dev : nullptr, ctx->stream_active ? ctx->stream_host : nullptr,
                                                    ctx->stream_active && ctx->stream_in_host ? ctx->progress_dev + milzma_ctx::kMaxSpans : nullptr,
-                                                   ctx->stream_active ? ctx->stream_ptrs : nullptr)
-                          : cls == kFast || cls == kFastLc4
-                              ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad, cls == kFastLc4,
-                                            static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u))
+                                                   ctx->stream_active ? ctx->stream_ptrs : nullptr,
+                                                   cls == kFastSpill ? static_cast<const uint8_t*>(ctx->scratch.p) : nullptr, uint32_t(slab_bytes))
+                          : is_fast
+                              ? launch_fast(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad,
+                                            static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u),
+                                            cls == kFastSpill ? static_cast<const uint8_t*>(ctx->scratch.p) : nullptr, uint32_t(slab_bytes))
                               : launch_generic(cls, d_units, d_order + i, m, d_in, d_out, d_results,
                                                         static_cast<uint16_t*>(ctx->scratch.p), spill_lclp, stream);
     if (!hip_ok(ctx, le, "kernel launch")) return false;
@@ -723,7 +753,8 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   std::vector<uint32_t> order[kNumLitClasses];
   if (resume) {  // only what the previous call parked, each unit in the class it was parked in (err_b: the instantiation's rows)
     for (uint32_t i = 0; i < n; i++)
-      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED) order[prev[i].err_b == 16 ? kFastLc4 : kFast].push_back(i);
+      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED)
+        order[(prev[i].err_b & 0x100) ? kFastSpill : kFast].push_back(i);
   } else {
     for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
   }
@@ -814,11 +845,11 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
   memcpy(results, ctx->pin_results.p, size_t(n) * sizeof(milzma_result));
 
   // Promotions: LZMA2 units whose chunks switched to properties outside their class's reach run
-  // again, from the start, in the next class up (fast -> fast/lc4, which covers every LZMA2-legal property set;
+  // again, from the start, in the next class up (fast -> fast with a literal-row slab, which covers every LZMA2-legal property set;
   // with MILZMA_KERNEL=generic: generic/LDS3 -> generic/LDS4).
   for (int round = 0; round < 2; round++) {
     std::vector<uint32_t> again;
-    LitClass next = ctx->use_fast ? kFastLc4 : kLitLds3;
+    LitClass next = ctx->use_fast && ctx->fast_spill ? kFastSpill : kLitLds3;
     for (uint32_t i = 0; i < n; i++) {
       if (round == 0 && results[i].status == MILZMA_ST_NEED_GENERIC) again.push_back(i);
       if (round == 1 && results[i].status == MILZMA_ST_NEED_LCLP && results[i].err_a <= 4) again.push_back(i);

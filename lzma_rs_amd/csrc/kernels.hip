@@ -40,14 +40,14 @@ hipError_t launch_generic(LitClass cls, const milzma_unit* d_units, const uint32
 
 // Blocks of a fast kernel the CURRENT device holds at once: occupancy API x CU count, asked once per device and kernel (the cache
 // is keyed by the device ordinal and guarded: the lanes' and the multi-device workers' threads come through here concurrently, and
-// devices of one node may differ in CU count / partition mode); the data-sheet figures -- 256 CUs x 16, or x 12 for the LC4
-// instantiation -- if the API fails.  Decides when the priority rotation starts and how many persistent waves a time-sliced launch
-// gets: a wrong value costs time, never correctness.
+// devices of one node may differ in CU count / partition mode); the data-sheet figure -- 256 CUs x 16 -- if the API fails.  Decides
+// when the priority rotation starts and how many persistent waves a time-sliced launch gets: a wrong value costs time, never
+// correctness.
 namespace {
-enum { kKernFast8 = 0, kKernFast16 = 1, kKernSliced8 = 2, kKernSliced16 = 3 };
+enum { kKernFast = 0, kKernSliced = 1 };
 uint32_t resident_blocks(int kern, uint32_t lds_pad) {
   static std::mutex mu;
-  static uint32_t cached[64][4] = {};
+  static uint32_t cached[64][2] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
@@ -58,16 +58,11 @@ uint32_t resident_blocks(int kern, uint32_t lds_pad) {
     std::lock_guard<std::mutex> lock(mu);
     if (cached[dev][kern]) return cached[dev][kern];
   }
-  uint32_t r = (kern & 1) ? 256u * 12u : 256u * 16u;
+  uint32_t r = 256u * 16u;
   int per_cu = 0;
   hipDeviceProp_t prop;
-  hipError_t e;
-  switch (kern) {
-    case kKernFast8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<8>, int(kWave), lds_pad); break;
-    case kKernFast16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel<16>, int(kWave), lds_pad); break;
-    case kKernSliced8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<8>, int(kWave), lds_pad); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel<16>, int(kWave), lds_pad); break;
-  }
+  const hipError_t e = kern == kKernFast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_kernel, int(kWave), lds_pad)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_fast_asm_sliced_kernel, int(kWave), lds_pad);
   if (e == hipSuccess && per_cu > 0 && dev >= 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     r = uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
   else
@@ -80,48 +75,44 @@ uint32_t resident_blocks(int kern, uint32_t lds_pad) {
 }
 }  // namespace
 
-uint32_t fast_resident_blocks(bool lc4, uint32_t lds_pad) { return resident_blocks(lc4 ? kKernFast16 : kKernFast8, lds_pad); }
+uint32_t fast_resident_blocks(uint32_t lds_pad) { return resident_blocks(kKernFast, lds_pad); }
 
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag) {
+                       milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, uint32_t* d_flag, const uint8_t* d_slab,
+                       uint32_t slab_bytes) {
   if (n == 0) return hipSuccess;
   // d_flag: a device word per launch that the launch's last block raises: the waves rotate their priorities (finish
   // together) only once no block is waiting for a slot any more; until then staggered finishes refill slots early
   // (5120 streams: 13.5 vs 11.2 GB/s).  A launch that is a whole number of rounds rotates from the start (8192: 17.2 vs 16.2).
-  const uint32_t resident = fast_resident_blocks(lc4, lds_pad);
+  const uint32_t resident = fast_resident_blocks(lds_pad);
   if (hipError_t e = hipMemsetAsync(d_flag, n % resident == 0 ? 1 : 0, sizeof(uint32_t), stream); e != hipSuccess) return e;
   // lds_pad: unused dynamic LDS (MILZMA_LDS_PAD, tuning only): what an LDS-resident window of that size would do to occupancy
-  if (lc4)
-    hipLaunchKernelGGL(decode_fast_asm_kernel<16>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results,
-                       d_flag);
-  else
-    hipLaunchKernelGGL(decode_fast_asm_kernel<8>, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results,
-                       d_flag);
+  hipLaunchKernelGGL(decode_fast_asm_kernel, dim3(n), dim3(kWave), lds_pad, stream, d_units, d_order, n, d_in, d_out, d_results, d_flag, d_slab,
+                     slab_bytes);
   return hipGetLastError();
 }
 
-// one stride for both instantiations (the larger one's): the parked states of a batch are indexed by unit, whatever class it ran in
-size_t slice_ctx_bytes() { return size_t(std::max(SliceCtx<16>::kDwords, SliceCtx<8>::kDwords)) * sizeof(uint32_t); }
+// the parked states of a batch are indexed by unit
+size_t slice_ctx_bytes() { return size_t(SliceCtx::kDwords) * sizeof(uint32_t); }
 size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap) * sizeof(uint32_t); }
 
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                              milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, bool lc4, uint32_t* d_flag, void* d_queue,
+                              milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, uint32_t* d_flag, void* d_queue,
                               uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t span_bytes,
-                              uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready, const uint64_t* host_ptrs) {
+                              uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready, const uint64_t* host_ptrs,
+                              const uint8_t* d_slab, uint32_t slab_bytes) {
   if (n == 0) return hipSuccess;
   auto* q = static_cast<SliceQueue*>(d_queue);
   auto* ring = reinterpret_cast<uint32_t*>(q + 1);
   if (hipError_t e = hipMemsetAsync(d_flag, 1, sizeof(uint32_t), stream); e != hipSuccess) return e;  // all waves start together: rotate
   // persistent waves: what the chip holds of THIS kernel (it keeps more registers alive than the ordinary one; never more than that one's)
-  const uint32_t resident = std::min(fast_resident_blocks(lc4, lds_pad), resident_blocks(lc4 ? kKernSliced16 : kKernSliced8, lds_pad));
+  const uint32_t resident = std::min(fast_resident_blocks(lds_pad), resident_blocks(kKernSliced, lds_pad));
   const uint32_t waves = std::min(n, resident);
   hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
                      d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem), grow ? 1u : 0u,
-                     uint32_t(slice_ctx_bytes() / sizeof(uint32_t)), progress ? span_bytes : 0u, n_spans, progress, host_out, progress ? in_ready : nullptr, progress ? host_ptrs : nullptr);
-  if (lc4)
-    hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<16>, dim3(waves), dim3(kWave), lds_pad, stream, q);
-  else
-    hipLaunchKernelGGL(decode_fast_asm_sliced_kernel<8>, dim3(waves), dim3(kWave), lds_pad, stream, q);
+                     uint32_t(slice_ctx_bytes() / sizeof(uint32_t)), progress ? span_bytes : 0u, n_spans, progress, host_out, progress ? in_ready : nullptr, progress ? host_ptrs : nullptr,
+                     d_slab, slab_bytes);
+  hipLaunchKernelGGL(decode_fast_asm_sliced_kernel, dim3(waves), dim3(kWave), lds_pad, stream, q);
   return hipGetLastError();
 }
 

@@ -29,8 +29,8 @@ def _hdr(comp):
 
 @pytest.fixture(scope="module")
 def loops():
-    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "lc4": asmprog.AsmLoop(lp0=False, pb4=True, lc4=True),
-         "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}
+    m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "lc4": asmprog.AsmLoop(lp0=False, pb4=True, hbm=True),
+         "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}     # ("lc4": lc + lp = 4 runs in the HBM variant since round 4)
     yield m
     for a in set(m.values()):
         a.close()
@@ -105,9 +105,10 @@ def test_marker_before_a_declared_size(loops):
 
 
 @pytest.mark.parametrize("lc,lp,pb", [(4, 0, 2), (0, 4, 0), (2, 2, 4)])
-def test_emulated_lc4_rows_in_vgprs(loops, lc, lp, pb):
-    """lc + lp = 4: the matched-literal sub-tables of literal rows 12..15 live in VGPRs (rows 0..11 in LDS).  Bytes >= 0xC0 before
-    a literal that follows a match select those rows: binary data with many short matches goes through both homes."""
+def test_emulated_lc4_through_the_row_caches(loops, lc, lp, pb):
+    """lc + lp = 4 (16 literal rows) runs in the HBM variant since round 4: eight register rows and eight LDS rows cache the 16 rows
+    of the slab.  Binary data with many short matches makes plain and matched literals land in every row: both caches must miss,
+    evict (write back) and hit, and the output is the oracle's."""
     rnd = random.Random(lc * 10 + lp)
     blk = rnd.randbytes(4000)
     plain = b"".join(blk[i:i + rnd.randint(3, 40)] + rnd.randbytes(rnd.randint(1, 6)) for i in range(0, 3900, 17)) + \
@@ -119,10 +120,15 @@ def test_emulated_lc4_rows_in_vgprs(loops, lc, lp, pb):
     emu.reset_counts()
     emu.decode_raw(comp[13:], lc, lp, pb, 1 << 16, None, out_cap=len(plain) + 8)
     c, _ = emu.counts()
-    assert sum(int(c[i]) for i in range(len(c)) if emu.prog.region[i].startswith("LOvrow_load")) > 100
+    by_op = {}
+    for i, text in enumerate(emu.prog.text):
+        by_op[text.split()[0]] = by_op.get(text.split()[0], 0) + int(c[i])
+    # plain rows: loads (misses) and stores (evictions) of 8 bytes per lane; matched rows: 16 bytes per lane
+    assert by_op["buffer_load_dwordx2"] > 50 and by_op["buffer_store_dwordx2"] > 30
+    assert by_op["buffer_load_dwordx4"] > 20 and by_op["buffer_store_dwordx4"] > 10
 
 
-@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # the LP0, GEN, PB4 and LC4 variants of the loop
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # the LP0, GEN, PB4 and HBM variants of the loop
 def test_emulated_reader_at_every_cut(loops, lc, lp, pb):
     """the loop's reader (end-aligned last window, "reader at EOF" state) against the oracle for EVERY prefix of short streams: known
     size, unknown size with marker, unknown size without marker (finished only if the reader is at EOF with code == 0), lengths
@@ -188,3 +194,36 @@ def test_emulated_loop_yields_at_quanta(loops, lc, lp, pb):
             if q == 1 << 20:
                 assert r["yields"] == 0
     assert most > 1000                           # quantum 1 on random data: a yield at (nearly) every symbol
+
+
+def test_emulated_hbm_variant_lclp_above_four():
+    """The HBM variant of the loop (lc + lp > 4: the 2^(lc+lp) literal rows in a slab in memory, eight register rows and eight LDS
+    rows as direct-mapped caches over it, tags in two VGPRs' lanes): streams with real match structure for every kind of property set
+    it may meet (lc up to 8, lp up to 4, pb up to 4; also sets the other variants own, where it must agree with them), known and
+    marker-terminated, truncated, with a quantum that parks the walk every 2500 bytes -- against the oracle."""
+    import random
+    import lzma_enc as E
+    emu = asmprog.AsmLoop(lp0=False, pb4=True, hbm=True)
+    try:
+        rnd = random.Random(3)
+        for (lc, lp, pb) in [(8, 0, 2), (4, 4, 0), (5, 2, 4), (8, 4, 4), (3, 0, 2), (4, 0, 2), (0, 0, 0)]:
+            size = 90_000
+            plain = (W.make_plain("text", size - 30000, seed=lc * 100 + lp * 10 + pb) + rnd.randbytes(15000) + bytes(range(256)) * 58 + b"x" * 152)[:size]
+            for known in (True, False):
+                enc = E.LzmaSymbolEncoder(lc, lp, pb)
+                enc.encode(E.lz_parse(plain, dict_size=1 << 16))
+                if not known:
+                    enc.encode([("marker",)])
+                comp = E.lzma_header(lc, lp, pb, 1 << 16, len(plain) if known else None) + enc.finish()
+                ref = orc.lzma_decompress(comp)
+                assert ref.ok and ref.out == plain
+                for quantum in (None, 2500):
+                    r = emu.decode_raw(comp[13:], lc, lp, pb, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300, quantum=quantum)
+                    assert r["status"] == "OK" and r["out"] == plain and r["in_consumed"] + 13 == ref.in_consumed, (lc, lp, pb, known, quantum)
+                cut = comp[:len(comp) * 2 // 3]
+                ref = orc.lzma_decompress(cut)
+                r = emu.decode_raw(cut[13:], lc, lp, pb, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300)
+                assert r["status"] == "INPUT_EOF" and r["in_consumed"] + 13 == ref.in_consumed
+                assert r["out"][:len(ref.out)] == ref.out
+    finally:
+        emu.close()

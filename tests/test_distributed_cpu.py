@@ -118,18 +118,17 @@ def test_bench_refuses_more_gpus_than_present():
 
 
 def test_bench_traffic_only_from_records_of_this_kernel_source(tmp_path, monkeypatch):
-    """bench.py's roofline.traffic: the recorded PMC figure only if the record was taken on the kernel source being run, or names
-    this source compatible with its own (`also_valid_for`, with the reason -- which the line then repeats); anything else is null."""
+    """bench.py's roofline.traffic: the recorded PMC figure only if the record was taken on exactly the kernel source being run;
+    anything else is null -- a record cannot vouch for another source (round 3's `also_valid_for` is gone)."""
     import json
     sys.path.insert(0, ROOT)
     import bench
     prof = tmp_path / "profiles"
     prof.mkdir()
     rec = {"kernel_source_sha256": "aaaa", "derived": {"hbm_bytes_per_launch": 123.0}, "also_valid_for": {"bbbb": "no memory instruction changed"}}
-    (prof / "r03_pmc_lzma64k.json").write_text(json.dumps(rec))
+    (prof / (bench.PROFILE_ROUND + "_pmc_lzma64k.json")).write_text(json.dumps(rec))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("lzma64k", "aaaa") == (123.0, None)
-    val, note = bench.pmc_traffic("lzma64k", "bbbb")
-    assert val == 123.0 and "aaaa" in note and "no memory instruction changed" in note
+    assert bench.pmc_traffic("lzma64k", "bbbb") == (None, None)
     assert bench.pmc_traffic("lzma64k", "cccc") == (None, None)
     assert bench.pmc_traffic("dict8m", "aaaa") == (None, None)

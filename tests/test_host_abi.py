@@ -143,7 +143,7 @@ def test_asm_loop_wait_states():
     branches end a run: a taken branch is more than two wait states)."""
     inc = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "fast_loop_asm.inc")).read()
     runs = re.findall(r'#define MILZMA_FAST_LOOP_TEXT_\w+ \\\n((?:  ".*" \\\n)+)', inc)
-    assert len(runs) == 4  # LP0, GEN, PB4, LC4
+    assert len(runs) == 4  # LP0, GEN, PB4, HBM
     checked = 0
     for text in runs:
         lines = [m for m in re.findall(r'"([^"]*)\\n\\t"', text)]
@@ -194,8 +194,7 @@ def test_rust_shim_declares_the_header_abi():
 
 
 def test_asm_loops_sit_in_the_code_object_untouched():
-    """Every instance of the generated symbol loop (LP0 / GEN / PB4 in the <8> kernels, LC4 in the <16> ones; ordinary and time-sliced
-    instantiations: eight in all) is found in the built code object instruction for instruction -- so nothing of the compiler's, in
+    """Every instance of the generated symbol loop (LP0 / GEN / PB4 / HBM, in the ordinary and in the time-sliced kernel: eight in all) is found in the built code object instruction for instruction -- so nothing of the compiler's, in
     particular none of the scratch_ spill traffic the time-sliced instantiations carry around the loop, sits between a loop's first
     and last instruction.  The ordinary kernels must stay (nearly) scratch-free altogether; the sliced ones are bounded."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -208,4 +207,4 @@ def test_asm_loops_sit_in_the_code_object_untouched():
             assert m["private_segment_fixed_size"] <= 2048, (name, m)
         else:
             assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
-        assert m["vgpr_count"] <= (128 if "ILi8E" in name else 168), (name, m)     # 4 / 3 waves per SIMD
+        assert m["vgpr_count"] <= 128, (name, m)     # four waves per SIMD

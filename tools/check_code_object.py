@@ -69,8 +69,8 @@ def disassemble(co):
 def generated_variants():
     import gen_fast_loop as G
     out = {}
-    for name, lp0, pb4, lc4 in (("LP0", True, False, False), ("GEN", False, False, False), ("PB4", False, True, False), ("LC4", False, True, True)):
-        g = G.Gen(lp0, pb4, lc4)
+    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)):
+        g = G.Gen(lp0, pb4, hbm=(name == "HBM"))
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
@@ -93,7 +93,7 @@ def check(so):
     for fname, mn in funcs.items():
         if "decode_fast_asm" not in fname:
             continue
-        want = ["LC4"] if "ILi16E" in fname else ["LP0", "GEN", "PB4"]
+        want = ["LP0", "GEN", "PB4", "HBM"]
         anchors = [i for i, x in enumerate(mn) if x == "s_getpc_b64"]
         found = []
         for a in anchors:

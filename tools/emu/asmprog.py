@@ -186,13 +186,13 @@ def classify(text):
 class AsmLoop:
     """One wavefront running the generated loop on a raw LZMA stream."""
 
-    def __init__(self, lp0=True, gen_module=None, pb4=False, lc4=False):
+    def __init__(self, lp0=True, gen_module=None, pb4=False, hbm=False):
         import gen_fast_loop as G
         self.G = gen_module or G
         G = self.G
-        g = G.Gen(lp0, pb4, lc4)
+        self.hbm = hbm
+        g = G.Gen(lp0, pb4, hbm=hbm)
         self.lit_regs, self.ps0 = G.LIT_REGS, int(G.PS0[1:])  # (this variant's fixed register numbering)
-        self.mvbase = G.MVBASE
         g.build()
         lines = g.main + g.cold + getattr(g, "cold2", []) + g.stubs
         g.cur = lines
@@ -204,7 +204,7 @@ class AsmLoop:
         for name in G.OPS_INOUT_S + G.OPS_IN_S:
             if name in self.regmap:
                 continue
-            if name in ("in_rsrc", "out_rsrc"):
+            if name in ("in_rsrc", "out_rsrc", "lit_rsrc"):
                 s_next = (s_next + 3) & ~3
                 self.regmap[name] = "s[%d:%d]" % (s_next, s_next + 3)
                 s_next += 4
@@ -277,7 +277,11 @@ class AsmLoop:
         IN0 = 64  # (bytes 0..3 of the emulated memory: the "last block has started" flag, set)
         in_span = (in_len + 63 + 128) & ~63
         OUT0 = IN0 + in_span + 64
-        mem = np.zeros(OUT0 + out_cap + 512, dtype=np.uint8)
+        SLAB0 = (OUT0 + out_cap + 512 + 255) & ~255
+        slab_bytes = (0x600 << (lc + lp)) if self.hbm else 0
+        mem = np.zeros(SLAB0 + slab_bytes + 64, dtype=np.uint8)
+        if slab_bytes:     # every probability 0x400 (the host memsets the slab before the launch)
+            mem[SLAB0:SLAB0 + slab_bytes].view(np.uint16)[:] = 0x400
         mem[IN0:IN0 + in_len] = np.frombuffer(bytes(payload), dtype=np.uint8)
         mem[0] = 1
         if "flagptr" in self.regmap:
@@ -304,13 +308,15 @@ class AsmLoop:
             self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
         for i in range(4):
             self.vset(self.ps0 + i, 0x400)
-        if self.mvbase:      # matched rows that live in VGPRs: LC4's rows 12..15
-            for i in range(16):
-                self.vset(self.mvbase + i, 0x04000400)
         lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
         self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
         self.vset(self._vidx("v_lane"), lane)
         self.vset(self._vidx("pend_val"), 0)
+        if "vtag" in self.regmap:   # (the walked row 0 owns its slot; everything else empty)
+            self.vset(self._vidx("vtag"), np.where(lane == 0, 0, 0xFFFFFFFF).astype(np.uint32))
+            self.vset(self._vidx("vtagm"), 0xFFFFFFFF)
+        if "lit_rsrc" in self.regmap:
+            self.set_rsrc("lit_rsrc", SLAB0, slab_bytes)
         # reader: seek(0, in_len), then rc_init
         wbase, off, lim = 0, 0, in_len
         if in_len < 5:

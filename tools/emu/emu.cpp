@@ -51,6 +51,7 @@ struct Ins {
   X(v_alignbit_b32) X(v_or3_b32) X(v_xad_u32) X(v_sub_co_u32) X(v_mbcnt_lo_u32_b32) X(v_mbcnt_hi_u32_b32)              \
   X(ds_read_b128) X(ds_write_b128) X(ds_read_b32) X(ds_write_b32) X(ds_read_u8) X(ds_write_b8) X(ds_read_b64)          \
   X(ds_write_b64) X(buffer_load_ubyte) X(buffer_store_byte) X(buffer_load_dword) X(buffer_store_dword)                 \
+  X(buffer_load_dwordx2) X(buffer_load_dwordx4) X(buffer_store_dwordx2) X(buffer_store_dwordx4)                        \
   X(ds_bpermute_b32)
 
 enum Op : int {
@@ -451,6 +452,41 @@ long run(Emu& e, int start, long max_steps) {
           tmp[l] = val;
         }
         memcpy(e.v[I.a[0].val], tmp, sizeof(tmp));
+      } break;
+      case OP_buffer_load_dwordx2:
+      case OP_buffer_load_dwordx4: {  // v[d : d + n - 1], vaddr, srsrc, soffset   (offen): dword k of a lane into register d + k
+        Rsrc r = rsrc(e, I.a[2]);
+        uint32_t so = rs(e, I.a[3]);
+        const int nd = I.op == OP_buffer_load_dwordx2 ? 2 : 4;
+        uint32_t addr[64];
+        memcpy(addr, e.v[I.a[1].val], sizeof(addr));
+        for (int l = 0; l < 64; l++) {
+          uint64_t off = uint64_t(addr[l]) + so;
+          for (int k = 0; k < nd; k++) {
+            uint32_t val = 0;
+            if (off + 4 * k + 4 <= r.records) {
+              uint64_t a = r.base + off + 4 * k;
+              if (a + 4 > e.mem_size) { e.err = "buffer load outside the emulated memory"; break; }
+              memcpy(&val, e.mem + a, 4);
+            }
+            e.v[I.a[0].val + k][l] = val;
+          }
+        }
+      } break;
+      case OP_buffer_store_dwordx2:
+      case OP_buffer_store_dwordx4: {
+        Rsrc r = rsrc(e, I.a[2]);
+        uint32_t so = rs(e, I.a[3]);
+        const int nd = I.op == OP_buffer_store_dwordx2 ? 2 : 4;
+        for (int l = 0; l < 64; l++) {
+          uint64_t off = uint64_t(e.v[I.a[1].val][l]) + so;
+          for (int k = 0; k < nd; k++)
+            if (off + 4 * k + 4 <= r.records) {
+              uint64_t a = r.base + off + 4 * k;
+              if (a + 4 > e.mem_size) { e.err = "buffer store outside the emulated memory"; break; }
+              memcpy(e.mem + a, &e.v[I.a[0].val + k][l], 4);
+            }
+        }
       } break;
       case OP_buffer_store_byte:
       case OP_buffer_store_dword: {  // vdata, vaddr, srsrc, soffset   (offen); lanes in ascending order

@@ -2,8 +2,10 @@
 """Generates lzma_rs_amd/csrc/fast_loop_asm.inc: the LZMA symbol loop of the fast kernel as ONE gfx950
 inline-asm statement per variant (text + operand lists), so that nothing in the hot loop is left to hipcc's
 register allocator / block placement (rocprof on a C++ loop: 45 % of issued instructions were phi copies and
-other compiler glue).  Variants: LP0 (lp == 0, pb <= 2), GEN (any lp, pb <= 2), PB4 (pb 3 / 4), LC4 (lc + lp = 4,
-own register numbering, used by the <16> instantiation of the kernel).
+other compiler glue).  Variants, all with the same register numbering (one kernel, 128 VGPRs, four waves per SIMD): LP0 (lp == 0,
+pb <= 2: the headline), GEN (any lp, pb <= 2), PB4 (pb 3 / 4) -- these three for lc + lp <= 3 -- and HBM (lc + lp >= 4, any pb: the
+literal rows in a slab in memory behind eight cached rows; round 4 -- it replaced the LC4 variant and its 152-VGPR kernel, which ran
+lc + lp = 4 at three waves per SIMD: 11.9 GB/s against 15.1 now, profiles/r04_lclp_classes.txt).
 
 What the loop does is DecoderState::process_mode(Finish) (src/decode/lzma.rs:435-524) with
 decode_literal (526-561), decode_distance (563-592), LenDecoder::decode (rangecoder.rs:256-269),
@@ -149,31 +151,25 @@ _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt
            DVT=114, DVA=115, DVX=116, c2017=117, c2048=118, VSTT=119)  # temporaries of deferred updates; the constants 2017 and 2048
 if PAD_V:
     _V0["vpad"] = 111
-V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE = {}, "", "", "", [], 16, None
-VROW0 = 12   # LC4: first matched row that lives in VGPRs
+V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
 LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
 
 
-def set_layout(lc4):
-    """Fixed VGPR numbering of a variant: the plain literal table at v64.. (16 dwords for lc + lp <= 3, 32 for lc + lp = 4),
-    then the four pos_slot trees (PS0..), then the temporaries and per-lane constants."""
-    global V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS, MVBASE, LIT1
-    off = 16 if lc4 else 0
-    LIT_REGS = 32 if lc4 else 16
+def set_layout():
+    """Fixed VGPR numbering: the plain literal table (eight rows, 16 dwords) at v64.., then the four pos_slot trees (PS0..), then the
+    temporaries and per-lane constants."""
+    global V, MROW, PS0, PS0M2, CLOBBER_V, LIT1
     LIT1 = "v%d" % (VBASE + LIT_REGS // 2) if LITSPLIT else "v%d" % (VBASE + 1)
     V.clear()
-    off += VBASE - 64
+    off = VBASE - 64
     V.update({k: "v%d" % (n + off) for k, n in _V0.items()})
     MROW = "v[%d:%d]" % (84 + off, 87 + off)
     PS0 = "v%d" % (80 + off)        # pos_slot trees for len_state 0..3
     PS0M2 = "v%d" % (78 + off)      # PS0 - 2: indexed with len_state + 2
     CLOBBER_V = sorted(set(V.values()), key=lambda r: int(r[1:]))
-    # LC4: the matched-literal sub-tables of rows 12..15 live in 16 VGPRs (fixed operands, s_set_gpr_idx indexed), rows 0..11 in
-    # LDS: 12 KiB per wave instead of 16 -> 13 blocks per CU fit, and the 151 VGPRs allow 12 (3 per SIMD); with 16 KiB it was 9
-    MVBASE = (max(int(r[1:]) for r in V.values()) + 1) if lc4 else None
 
 
-set_layout(False)
+set_layout()
 CLOBBER_S = sorted(set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ DM, the refill return address)
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
@@ -184,12 +180,13 @@ OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "
 OPS_INOUT_V = ["m_ismatch", "m_rep", "m_rep0long", "m_align", "m_posdec_a", "m_posdec_b", "m_len_low", "m_len_mid",
                "m_len_h0", "m_len_h1", "m_len_h2", "m_len_h3", "m_rlen_low", "m_rlen_mid", "m_rlen_h0", "m_rlen_h1",
                "m_rlen_h2", "m_rlen_h3", "u0", "u1", "u2", "u3", "winb", "winb_next", "pend_val", "tbl_a", "tbl_b",
+               "vtag", "vtagm",   # hbm variant: whose row each of the eight register / LDS row slots holds (lanes 0..7; -1: none)
                # pb 3 / 4 (PB4 variant): position states 4..15
                "m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b",
                "m_rlen_mid_b"]
 PB4_ONLY_V = ["m_ismatch_b", "m_ismatch_c", "m_rep0long_b", "m_rep0long_c", "m_len_low_b", "m_len_mid_b", "m_rlen_low_b", "m_rlen_mid_b"]
 OPS_IN_S = ["out_lim", "safe_len", "target", "qtop", "known", "dict_size", "lc", "lc8", "lpmask", "pbmask", "in_rsrc",
-            "out_rsrc", "ldsbase", "flagptr"]
+            "out_rsrc", "ldsbase", "flagptr", "lit_rsrc"]   # lit_rsrc: the literal rows' slab in HBM (hbm variant: lc + lp > 4)
 OPS_IN_V = ["v_lane"]
 FIXED_OPERANDS = {"range": "s66", "code": "s67"}   # an aligned pair, for s_cselect_b64
 RC = "s[66:67]"
@@ -230,10 +227,16 @@ class QE(tuple):
 
 
 class Gen:
-    def __init__(self, lp0, pb4=False, lc4=False):
-        set_layout(lc4)  # (lc4: lc + lp = 4 -- 16 literal rows; same code, other register numbers and 16 KiB of LDS rows)
-        self.lc4 = lc4
-        self.vrow0 = VROW0 if lc4 else None   # first matched row that lives in VGPRs (None: all in LDS)
+    def __init__(self, lp0, pb4=False, hbm=False):
+        set_layout()
+        # hbm: lc + lp > 4 (legal in a .lzma header, lzma.rs:96-161; up to 4096 literal rows of 1536 bytes: 256 plain probabilities +
+        # 2 x 256 matched ones).  The rows live in a slab in HBM (lit_rsrc: row r at r * 1536 -- 512 bytes plain, packed as in the
+        # registers, then 1024 bytes matched, as in LDS); the eight row registers and the eight LDS rows become direct-mapped caches
+        # (slot = row & 7) with their tags in the lanes of vtag / vtagm (-1: empty).  A row comes in when a literal needs it and the
+        # slot holds another (one load + wait: the price of a miss), the evicted one goes back with a store nobody waits for.  The
+        # row the literal walk is on (u0..u3) owns its slot.  Needs LITSPLIT's layout (gpr index = slot).
+        self.hbm = hbm
+        assert not hbm or (pb4 and not lp0 and LITSPLIT)
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
         # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
@@ -742,7 +745,7 @@ class Gen:
         e, L = self.e, self.L
         e("s_getpc_b64 " + JBASE)
         self.lab("base")
-        vid = 4 if self.lc4 else 3 if self.pb4 else 1 if self.lp0 else 2  # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
+        vid = 4 if self.hbm else 3 if self.pb4 else 1 if self.lp0 else 2  # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
         e("s_cmp_eq_u32 {tbl_ready}, %d" % vid)             #  unit may change lp, and with it the variant, between chunks)
         e("s_cbranch_scc1 " + L("tbl_done"))
         bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
@@ -907,8 +910,62 @@ class Gen:
         e("v_readfirstlane_b32 {prev}, {VT0}")
         e("s_branch " + self.L(ret))
 
+    def row_swap_stub_hbm(self, name, ret):
+        """hbm variant: park the walked row in its slot, bring the new row's slot up to date (tag check; on a miss: the slot's old
+        row back to the slab, the new one in), unpack it"""
+        e, L = self.e, self.L
+        k = self.new("HS")
+        with self.in_cold():
+            self.lab(name)
+            e("s_and_b32 {t3}, {row}, 7")                       # the new row's slot
+            e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
+            e("v_lshl_or_b32 {VT1}, {u3}, 16, {u2}")
+            e("s_and_b32 {t0}, {cur_row}, 7")
+            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
+            e("v_mov_b32 " + LIT0 + ", {VT0}")
+            e("v_mov_b32 " + LIT1 + ", {VT1}")
+            e("s_set_gpr_idx_off")
+            e("v_readlane_b32 {t1}, {vtag}, {t3}")              # whose row the slot holds
+            e("s_cmp_eq_u32 {t1}, {row}")
+            e("s_cbranch_scc1 " + L(k + "hit"))
+            e("s_cmp_eq_u32 {t1}, -1")
+            e("s_cbranch_scc1 " + L(k + "load"))
+            e("s_set_gpr_idx_on {t3}, gpr_idx(SRC0)")           # the evicted row goes back (a store nobody waits for)
+            e("v_mov_b32 {VT0}, " + LIT0)
+            e("v_mov_b32 {VT1}, " + LIT1)
+            e("s_set_gpr_idx_off")
+            e("s_mul_i32 {t2}, {t1}, 0x600")
+            e("v_lshl_add_u32 {VA}, {v_lane}, 3, {t2}")
+            e("buffer_store_dwordx2 v[%d:%d], {VA}, {lit_rsrc}, 0 offen" % (int(V["VT0"][1:]), int(V["VT1"][1:])))
+            self.lab(k + "load")
+            e("s_mul_i32 {t2}, {row}, 0x600")
+            e("v_lshl_add_u32 {VA}, {v_lane}, 3, {t2}")
+            e("buffer_load_dwordx2 v[%d:%d], {VA}, {lit_rsrc}, 0 offen" % (int(V["VT0"][1:]), int(V["VT1"][1:])))
+            e("s_mov_b32 m0, {t3}")
+            e("s_waitcnt vmcnt(0)")
+            e("v_writelane_b32 {vtag}, {row}, m0")
+            e("s_set_gpr_idx_on {t3}, gpr_idx(DST)")
+            e("v_mov_b32 " + LIT0 + ", {VT0}")
+            e("v_mov_b32 " + LIT1 + ", {VT1}")
+            e("s_set_gpr_idx_off")
+            e("s_branch " + L(k + "unpack"))
+            self.lab(k + "hit")
+            e("s_set_gpr_idx_on {t3}, gpr_idx(SRC0)")
+            e("v_mov_b32 {VT0}, " + LIT0)
+            e("v_mov_b32 {VT1}, " + LIT1)
+            e("s_set_gpr_idx_off")
+            self.lab(k + "unpack")
+            e("v_and_b32 {u0}, 0xffff, {VT0}")
+            e("v_lshrrev_b32 {u1}, 16, {VT0}")
+            e("v_and_b32 {u2}, 0xffff, {VT1}")
+            e("v_lshrrev_b32 {u3}, 16, {VT1}")
+            e("s_mov_b32 {cur_row}, {row}")
+            e("s_branch " + self.L(ret))
+
     def row_swap_stub(self, name, ret):
         """out of line: park the cached literal row, unpack the new one (cur_row -> row)"""
+        if self.hbm:
+            return self.row_swap_stub_hbm(name, ret)
         e = self.e
         with self.in_cold():
             self.lab(name)
@@ -1017,47 +1074,50 @@ class Gen:
             self.bit(R("u2"), R("sym"), cmp_lane=V["VLANE128"], defer=False)
             self.literal_epilogue()                      # (its own copy: one taken branch instead of two)
 
+    def mrow_load_hbm(self):
+        """hbm variant: the LDS rows are a cache (slot = row & 7, tags in vtagm); MROW = the row's matched sub-tables"""
+        e, L = self.e, self.L
+        e("s_and_b32 {t0}, {row}, 7")
+        e("v_lshl_add_u32 {VA}, {t0}, 10, {VL16}")
+        e("s_mul_i32 {t2}, {row}, 0x600")
+        e("s_add_u32 {t2}, {t2}, 0x200")
+        e("s_nop 1")
+        e("v_readlane_b32 {t1}, {vtagm}, {t0}")
+        e("s_cmp_lg_u32 {t1}, {row}")
+        e("s_cbranch_scc1 " + L("Omrow_miss"))
+        e("ds_read_b128 " + MROW + ", {VA}")
+        e("s_waitcnt lgkmcnt(0)")
+        self.lab("lm_b")
+        with self.in_cold():
+            self.lab("Omrow_miss")
+            e("s_cmp_eq_u32 {t1}, -1")
+            e("s_cbranch_scc1 " + L("Omrow_get"))
+            e("ds_read_b128 " + MROW + ", {VA}")                 # the evicted row goes back to the slab
+            e("s_mul_i32 {t1}, {t1}, 0x600")
+            e("s_add_u32 {t1}, {t1}, 0x200")
+            e("v_lshl_add_u32 {VT2}, {v_lane}, 4, {t1}")
+            e("s_waitcnt lgkmcnt(0)")
+            e("buffer_store_dwordx4 " + MROW + ", {VT2}, {lit_rsrc}, 0 offen")
+            self.lab("Omrow_get")
+            e("v_lshl_add_u32 {VT2}, {v_lane}, 4, {t2}")
+            e("buffer_load_dwordx4 " + MROW + ", {VT2}, {lit_rsrc}, 0 offen")
+            e("s_mov_b32 m0, {t0}")
+            e("s_waitcnt vmcnt(0)")
+            e("v_writelane_b32 {vtagm}, {row}, m0")              # (the LDS slot itself is written by mrow_store, after the literal)
+            e("s_branch " + L("lm_b"))
+
     def mrow_load(self):
         """MROW = the matched sub-tables of literal row `row` (4 dwords per lane)"""
         e, L = self.e, self.L
-        if self.vrow0 is not None:
-            e("s_cmpk_ge_u32 {row}, %d" % self.vrow0)
-            e("s_cbranch_scc1 " + L("Ovrow_load"))
+        if self.hbm:
+            return self.mrow_load_hbm()
         e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
         e("ds_read_b128 " + MROW + ", {VA}")
         e("s_waitcnt lgkmcnt(0)")
-        if self.vrow0 is not None:
-            self.lab("lm_b")
-            with self.in_cold():
-                self.lab("Ovrow_load")
-                e("s_sub_u32 {t0}, {row}, %d" % self.vrow0)
-                e("s_lshl_b32 {t0}, {t0}, 2")
-                e("s_set_gpr_idx_on {t0}, gpr_idx(SRC0)")
-                for k in range(4):
-                    e("v_mov_b32 v%d, v%d" % (int(MROW[2:MROW.index(":")]) + k, MVBASE + k))
-                e("s_set_gpr_idx_off")
-                e("s_branch " + L("lm_b"))
 
     def mrow_store(self):
-        """the row back where it lives (clobbers SCC and t0 where some rows live in VGPRs)"""
-        e, L = self.e, self.L
-        if self.vrow0 is None:
-            e("ds_write_b128 {VA}, " + MROW)
-            return
-        k = self.new("VS")
-        e("s_cmpk_ge_u32 {row}, %d" % self.vrow0)
-        e("s_cbranch_scc1 " + L(k))
-        e("ds_write_b128 {VA}, " + MROW)
-        self.lab(k + "r")
-        with Gen._Into(self, self.cold2):
-            self.lab(k)
-            e("s_sub_u32 {t0}, {row}, %d" % self.vrow0)
-            e("s_lshl_b32 {t0}, {t0}, 2")
-            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
-            for j in range(4):
-                e("v_mov_b32 v%d, v%d" % (MVBASE + j, int(MROW[2:MROW.index(":")]) + j))
-            e("s_set_gpr_idx_off")
-            e("s_branch " + L(k + "r"))
+        """the row back to its LDS row (hbm variant: its LDS slot)"""
+        self.e("ds_write_b128 {VA}, " + MROW)
 
     def literal_row(self, tag):
         e, L = self.e, self.L
@@ -1652,9 +1712,8 @@ class Gen:
 
 def main():
     texts, clobbers, fixeds = {}, {}, {}
-    for name, lp0, pb4, lc4 in (("LP0", True, False, False), ("GEN", False, False, False), ("PB4", False, True, False),
-                                ("LC4", False, True, True)):
-        g = Gen(lp0, pb4, lc4)
+    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)):
+        g = Gen(lp0, pb4, hbm=(name == "HBM"))
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
@@ -1662,13 +1721,12 @@ def main():
         texts[name] = lines
         clobbers[name] = list(CLOBBER_V)
         fixeds[name] = (['"+{v%d}"(d.lit[%d])' % (VBASE + i, i) for i in range(LIT_REGS)] +
-                        ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)] +
-                        (['"+{v%d}"(d.mrowv[%d])' % (MVBASE + i, i) for i in range(16)] if MVBASE else []))
+                        ['"+{v%d}"(d.posslot[%d])' % (int(PS0[1:]) + i, i) for i in range(4)])
     out = []
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
-    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, _GEN for any lp, _PB4 for pb 3 / 4 (any lp); _LC4 for lc + lp = 4 (any pb; its own")
-    out.append("// register numbering: MILZMA_FAST_LOOP_OUTPUTS_LC4 / _CLOBBERS_LC4, used by the LC4 instantiation of the kernel).")
+    out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, _GEN for any lp, _PB4 for pb 3 / 4 (any lp) -- lc + lp <= 3 --, _HBM for lc + lp >= 4 (any pb:")
+    out.append("// the literal rows in a slab in memory); one operand list for all of them.")
     out.append("// clang-format off")
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
@@ -1683,16 +1741,16 @@ def main():
         out.append('  ""')
     assert clobbers["LP0"] == clobbers["GEN"] and fixeds["LP0"] == fixeds["GEN"]
     assert clobbers["LP0"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["PB4"]
+    assert clobbers["LP0"] == clobbers["HBM"] and fixeds["LP0"] == fixeds["HBM"]
 
     def common(vnames):
         return ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
                 [('[%s] "+{v%d}"(d.%s)' % (n, PINV + i, n)) if PINV else ('[%s] "+v"(d.%s)' % (n, n)) for i, n in enumerate(vnames)])
     ins = ['[%s] "s"(d.%s)' % (n, n) for n in OPS_IN_S] + ['[%s] "v"(d.%s)' % (n, n) for n in OPS_IN_V]
-    for sfx, name in (("", "LP0"), ("_LC4", "LC4")):
-        out.append("#define MILZMA_FAST_LOOP_OUTPUTS%s \\" % sfx)
-        out.append("  " + ", \\\n  ".join(common(OPS_INOUT_V) + fixeds[name]))
-        out.append("#define MILZMA_FAST_LOOP_CLOBBERS%s \\" % sfx)
-        out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + clobbers[name]) + ', "vcc", "scc", "memory"')
+    out.append("#define MILZMA_FAST_LOOP_OUTPUTS \\")
+    out.append("  " + ", \\\n  ".join(common(OPS_INOUT_V) + fixeds["LP0"]))
+    out.append("#define MILZMA_FAST_LOOP_CLOBBERS \\")
+    out.append("  " + ", ".join('"%s"' % c for c in CLOBBER_S + clobbers["LP0"]) + ', "vcc", "scc", "memory"')
     out.append("#define MILZMA_FAST_LOOP_INPUTS \\")
     out.append("  " + ", \\\n  ".join(ins))
     out.append("#define MILZMA_FAST_LOOP_UNIFORM(d, rf) \\")
