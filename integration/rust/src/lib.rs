@@ -107,6 +107,90 @@ impl Drop for MultiContext {
     }
 }
 
+/// Unit-level calls on memory that already lives on the device (a pipeline that keeps files and output in HBM).
+impl Context {
+    /// `milzma_decode_units_ex`: `units[i]` names a slice of `d_in` / `d_out` (device pointers of this context's device).
+    /// With `ffi::MILZMA_DECODE_GROW` a unit that fills its slice before its stream ends comes back as
+    /// `status == MILZMA_ST_OUT_FULL` with `err_a == MILZMA_PARKED` -- its decoder state stays in the context; give it a
+    /// larger slice (`move_units` carries what it has written: that is its dictionary) and call again with
+    /// `ffi::MILZMA_DECODE_RESUME` and only the parked units.  Nothing is decoded twice.
+    ///
+    /// # Safety
+    /// `d_in` / `d_out` must be device allocations covering every slice the descriptors name, and the caller's own
+    /// work on them must have completed (the library uses streams of its own unless `hip_stream` is given).
+    pub unsafe fn decode_units_ex(
+        &self,
+        units: &[ffi::milzma_unit],
+        d_in: *const std::os::raw::c_void,
+        d_out: *mut std::os::raw::c_void,
+        hip_stream: *mut std::os::raw::c_void,
+        flags: u32,
+    ) -> error::Result<Vec<ffi::milzma_result>> {
+        let mut results: Vec<ffi::milzma_result> = (0..units.len()).map(|_| std::mem::zeroed()).collect();
+        let rc = ffi::milzma_decode_units_ex(self.raw, units.as_ptr(), units.len() as u32, d_in, d_out, results.as_mut_ptr(), hip_stream, flags);
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_decode_units_ex", ffi::milzma_last_error(self.raw)));
+        }
+        Ok(results)
+    }
+
+    /// `milzma_move_units`: `len[i]` bytes from `d_src + src_off[i]` to `d_dst + dst_off[i]`, on the device.
+    ///
+    /// # Safety
+    /// As for `decode_units_ex`; source and destination ranges must not overlap.
+    pub unsafe fn move_units(
+        &self,
+        d_src: *const std::os::raw::c_void,
+        src_off: &[u64],
+        d_dst: *mut std::os::raw::c_void,
+        dst_off: &[u64],
+        len: &[u64],
+        hip_stream: *mut std::os::raw::c_void,
+    ) -> error::Result<()> {
+        assert!(src_off.len() == len.len() && dst_off.len() == len.len());
+        let rc = ffi::milzma_move_units(self.raw, len.len() as u32, d_src, src_off.as_ptr(), d_dst, dst_off.as_ptr(), len.as_ptr(), hip_stream);
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_move_units", ffi::milzma_last_error(self.raw)));
+        }
+        Ok(())
+    }
+}
+
+impl MultiContext {
+    /// `milzma_multi_decode_units_rooted`: everything resident on device `root` (an index into `devices()`); the other
+    /// devices receive their shares device to device and send their output back the same way.
+    ///
+    /// # Safety
+    /// As for `Context::decode_units_ex`, with `d_in` / `d_out` on the root device.
+    pub unsafe fn decode_units_rooted(
+        &self,
+        root: u32,
+        units: &[ffi::milzma_unit],
+        d_in: *const std::os::raw::c_void,
+        d_out: *mut std::os::raw::c_void,
+    ) -> error::Result<Vec<ffi::milzma_result>> {
+        let mut results: Vec<ffi::milzma_result> = (0..units.len()).map(|_| std::mem::zeroed()).collect();
+        let rc = ffi::milzma_multi_decode_units_rooted(self.raw, root, units.as_ptr(), units.len() as u32, d_in, d_out, results.as_mut_ptr());
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_multi_decode_units_rooted", ffi::milzma_multi_last_error(self.raw)));
+        }
+        Ok(results)
+    }
+
+    /// Slowest device's (copy in, decode, copy back) of the last rooted call, milliseconds.
+    pub fn last_transfer_ms(&self) -> (f32, f32, f32) {
+        let (mut s, mut d, mut g) = (0f32, 0f32, 0f32);
+        unsafe { ffi::milzma_multi_last_transfer_ms(self.raw, &mut s, &mut d, &mut g) };
+        (s, d, g)
+    }
+}
+
+/// Returns pooled result buffers to the system until at most `keep_bytes` stay pooled; the bytes still pooled.
+/// (`Decoded::data` buffers are copied out of the pool by this shim, so a long-lived process may call this after a burst.)
+pub fn pool_trim(keep_bytes: usize) -> usize {
+    unsafe { ffi::milzma_pool_trim(keep_bytes) }
+}
+
 thread_local! {
     static DEFAULT_CTX: std::cell::RefCell<Option<Rc<Context>>> = std::cell::RefCell::new(None);
 }
