@@ -72,12 +72,25 @@ constexpr int ITER = 1500;
 // form B without the normalisation test, and with the test but without s_addc and without v_sub (floor of the form)
 #define STEP_NOT LSHR MUL SUB RL0 RL1 SSUB CSEL KEEP ADDC
 
+// ---- third batch: the normalisation stub (taken at EVERY decision here; in the loop: once per input byte, 0.12 per decision) -----------
+//   N0: as the loop has it: v_readlane of the input byte first -- the s_lshl_b64 behind it waits out the vector -> scalar hop.
+//   N1: the byte was read ahead into an SGPR (s82) by the previous stub; this stub's own v_readlane (for the NEXT normalisation) is its
+//       last instruction but the branch back, so its hop can run under the next decision's vector head.
+//   N2: N1 without the v_readlane at all (what hiding it completely would give).
+#define TAKEN "s_cmp_gt_u32 s66, 0\n\t" "s_cbranch_scc1 1f\n\t" "s_branch 2f\n\t" "1:\n\t"
+#define STEP_N0 LSHR MUL SUB RL0 RL1 SSUB CSEL KEEP ADDC TAKEN \
+  "v_readlane_b32 s82, %[x0], s81\n\t" "s_lshl_b64 s[84:85], s[84:85], 8\n\t" "s_or_b32 s85, s85, s82\n\t" "s_add_u32 s81, s81, 1\n\t" "s_cbranch_scc0 2f\n\t" "2:\n\t"
+#define STEP_N1 LSHR MUL SUB RL0 RL1 SSUB CSEL KEEP ADDC TAKEN \
+  "s_lshl_b64 s[84:85], s[84:85], 8\n\t" "s_or_b32 s85, s85, s82\n\t" "s_add_u32 s81, s81, 1\n\t" "s_cbranch_scc1 2f\n\t" "v_readlane_b32 s82, %[x0], s81\n\t" "s_branch 2f\n\t" "2:\n\t"
+#define STEP_N2 LSHR MUL SUB RL0 RL1 SSUB CSEL KEEP ADDC TAKEN \
+  "s_lshl_b64 s[84:85], s[84:85], 8\n\t" "s_or_b32 s85, s85, s82\n\t" "s_add_u32 s81, s81, 1\n\t" "s_cbranch_scc1 2f\n\t" "s_branch 2f\n\t" "2:\n\t"
+
 #define OPS                                                                                                          \
   : [vt] "=&v"(vt), [vb] "=&v"(vb), [vr] "=&v"(vr), [sym] "+s"(sym), [x0] "+v"(x0)                                   \
   : [p] "v"(prob), [pc] "v"(probc), [m7ff] "v"(m7ff)                                                                                   \
   : "s66", "s67", "s72", "s74", "s75", "s80", "s81", "s82", "s84", "s85", "s86", "scc", "vcc"
 
-enum { kB, kH3, kI, kH1, kH2, kP, kPS, kPI, kM1V, kM1S, kR11S, kVT, kA, kAR, kS1, kS2, kBSW, kM1R, kNOT, kCount };
+enum { kB, kH3, kI, kH1, kH2, kP, kPS, kPI, kM1V, kM1S, kR11S, kVT, kA, kAR, kS1, kS2, kBSW, kM1R, kNOT, kN0, kN1, kN2, kCount };
 
 template <int VAR>
 __global__ __launch_bounds__(64, 8) void chain(uint64_t* out, uint32_t seed) {
@@ -107,6 +120,9 @@ __global__ __launch_bounds__(64, 8) void chain(uint64_t* out, uint32_t seed) {
     else if constexpr (VAR == kBSW) RUN(STEP_BSW);
     else if constexpr (VAR == kM1R) RUN(STEP_M1R);
     else if constexpr (VAR == kNOT) RUN(STEP_NOT);
+    else if constexpr (VAR == kN0) RUN(STEP_N0);
+    else if constexpr (VAR == kN1) RUN(STEP_N1);
+    else if constexpr (VAR == kN2) RUN(STEP_N2);
   }
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (uint64_t(sym ^ prob ^ vt ^ vb ^ vr ^ x0) & 0);
@@ -137,8 +153,11 @@ int main(int argc, char**) {
   CHECK(hipMalloc(&d_out, 8192 * 8));
   std::vector<uint64_t> h(8192);
   const bool second = argc > 1;
+  const bool third = argc > 2;
   for (int pass = 0; pass < 2; pass++) {   // twice: run-to-run spread
-    if (!second) {
+    if (third) {
+      if (run<kB>("B", 11, d_out, h) || run<kN0>("N0", 18, d_out, h) || run<kN1>("N1", 19, d_out, h) || run<kN2>("N2", 18, d_out, h)) return 1;
+    } else if (!second) {
       if (run<kB>("B", 11, d_out, h) || run<kH1>("H1", 11, d_out, h) || run<kH2>("H2", 11, d_out, h) || run<kH3>("H3", 11, d_out, h) ||
           run<kI>("I", 11, d_out, h) || run<kP>("P", 12, d_out, h) || run<kPS>("PS", 12, d_out, h) || run<kPI>("PI", 12, d_out, h) ||
           run<kM1V>("B-1V", 10, d_out, h) || run<kM1S>("B-1S", 10, d_out, h) || run<kR11S>("R11S", 11, d_out, h) || run<kVT>("VT", 11, d_out, h))

@@ -44,7 +44,7 @@ struct Ins {
   X(s_getreg_b32) X(s_memtime) X(s_memrealtime) X(s_load_dword)                         \
   X(v_mov_b32) X(v_readlane_b32) X(v_readfirstlane_b32) X(v_writelane_b32) X(v_lshrrev_b32) X(v_lshlrev_b32)           \
   X(v_ashrrev_i32) X(v_add_u32) X(v_sub_u32) X(v_subrev_u32) X(v_and_b32) X(v_or_b32) X(v_xor_b32)                     \
-  X(v_mul_u32_u24) X(v_mad_u32_u24) X(v_mul_lo_u32) X(v_cndmask_b32) X(v_cmp_lt_u32) X(v_cmp_eq_u32) X(v_cmp_gt_u32)   \
+  X(v_mul_u32_u24) X(v_mad_u32_u24) X(v_mad_i32_i24) X(v_mul_lo_u32) X(v_cndmask_b32) X(v_cmp_lt_u32) X(v_cmp_eq_u32) X(v_cmp_gt_u32)   \
   X(v_cmp_ge_u32) X(v_cmp_le_u32) X(v_cmp_ne_u32) X(v_lshl_or_b32) X(v_lshl_add_u32) X(v_add_lshl_u32)                 \
   X(v_and_or_b32) X(v_add3_u32) X(v_bfe_u32) X(v_ffbh_u32) X(v_cvt_f32_u32) X(v_cvt_u32_f32) X(v_rcp_f32)              \
   X(v_add_f32) X(v_mul_f32) X(v_min_u32) X(v_max_u32) X(v_max_i32) X(v_movrels_b32) X(v_movreld_b32) X(v_bfi_b32)                   \
@@ -323,6 +323,11 @@ long run(Emu& e, int start, long max_steps) {
       case OP_v_mul_u32_u24: vop2(e, I, [](uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }); break;
       case OP_v_mul_lo_u32: vop2(e, I, [](uint32_t a, uint32_t b) { return a * b; }); break;
       case OP_v_mad_u32_u24: vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }); break;
+      case OP_v_mad_i32_i24:   // (operands: the low 24 bits, sign-extended)
+        vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) {
+          return uint32_t((int32_t(a << 8) >> 8) * (int32_t(b << 8) >> 8)) + c;
+        });
+        break;
       case OP_v_lshl_or_b32: vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) { return (a << (b & 31u)) | c; }); break;
       case OP_v_lshl_add_u32: vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) { return (a << (b & 31u)) + c; }); break;
       case OP_v_add_lshl_u32: vop3(e, I, [](uint32_t a, uint32_t b, uint32_t c) { return (a + b) << (c & 31u); }); break;

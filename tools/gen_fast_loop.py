@@ -126,6 +126,28 @@ LITSPLIT = os.environ.get("MILZMA_GEN_LITSPLIT", "1") == "1"
 # VBASE: first register of the loop's fixed VGPR block (literal table, pos_slot trees, temporaries and per-lane constants: 56 registers,
 # 72 for lc + lp = 4).  64 (the default) puts the block's top at v119.  (Round 3 also had VROW8 / NOPB4 for a five-waves-per-SIMD build of
 # the 8-row variants: +2.9 % for >= 5120 streams, nothing for 4096 -- removed in round 4, profiles/r03_kernel_ab.txt.)
+# SWAP2 (round 4): a row swap packs the walked row straight into its indexed registers and unpacks the new one straight out of them (11
+# instructions instead of 16: no staging moves).  DISPMAD: the entry into the direct-bit chains by two v_mad instead of two v_mul + add + sub
+# (the chain stride and the normalisation block's size as per-lane constants).
+SWAP2 = os.environ.get("MILZMA_GEN_SWAP2", "1") == "1"
+DISPMAD = os.environ.get("MILZMA_GEN_DISPMAD", "1") == "1"
+# DISP2 (needs DISPMAD): entry = B2 + clz * stride - ((n + clz) >> 3) * (8 * stride + normalisation size) with B2 = offset + n * stride
+# in tbl_b's upper 24 bits: three dependent vector instructions in front of the v_readlane instead of six, and tbl_a's v_readlane next to
+# the entry's (one vector -> scalar hop for both).
+DISP2 = os.environ.get("MILZMA_GEN_DISP2", "1") == "1"
+# SSHADOW: scalar bookkeeping that nothing waits for (state after a literal / a match, the rep rotation, the pos_slot tree's way back to
+# its register) is emitted in the NEXT decision's v_readlane shadow, where the wave would otherwise wait out the vector -> scalar hop
+# (a scalar instruction costs ~3 cycles there instead of ~6, experiments/microbench/shadow_slots.hip).  EARLYLDS: a matched literal's
+# row is requested from LDS as soon as the row is known, waited for where it is first used.
+SSHADOW = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_SSHADOW", ""))))   # of: state, rep, wb
+# NBPRE (needs EOFWRAP): the next input byte is read ahead into an SGPR (nb).  A normalisation shifts it in at once and reads the one
+# after it as its LAST instruction, so that v_readlane's vector -> scalar hop runs under the next decision's vector head instead of in
+# front of the stub's own scalar instructions (micro-benchmark: 80 -> 69 cycles per normalisation at four waves per SIMD).
+NBPRE = os.environ.get("MILZMA_GEN_NBPRE", "1") == "1"
+EARLYLDS = os.environ.get("MILZMA_GEN_EARLYLDS", "1") == "1"
+# MLGUARD: a matched literal's two distance checks (lzma.rs:541-546) behind the match guard gdist (<= min(len, dict_size)): one compare
+# instead of three; the exact checks out of line.
+MLGUARD = os.environ.get("MILZMA_GEN_MLGUARD", "1") == "1"
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
@@ -138,7 +160,7 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         pad="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         pad="s69", nb="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
 DM = "s[90:91]"     # lane mask of a deferred tree update (the constants 2017 / 2048 that used to live there are VGPRs now)
@@ -148,9 +170,14 @@ RET = "s[92:93]"  # return address of the window refill subroutine
 _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt=93, VR=94, VL16=95, VOOB=96, VKTOP=97, vx=98,
            VLANE64=99, VLANE128=100, VLANE192=101, vb=102, VSH6=103, VSH6M1=104, VSH5=105, VSH5M1=106, VSH4=107, VSH4M1=108,
            VLEVEL=109, va=110, vr=112, VLANEM1=113,
-           DVT=114, DVA=115, DVX=116, c2017=117, c2048=118, VSTT=119)  # temporaries of deferred updates; the constants 2017 and 2048
+           DVT=114, DVA=115, DVX=116, c2017=117, c2048=118, VSTT=119, VCH=111, VNDN=119, VB2=97)   # (VSTT only with STATE_TBL, vpad only with PAD_V)  # temporaries of deferred updates; the constants 2017 and 2048
+NBPRE = NBPRE and EOFWRAP and not PAD_S
 if PAD_V:
     _V0["vpad"] = 111
+    DISPMAD = False
+if STATE_TBL:
+    DISPMAD = False
+DISP2 = DISP2 and DISPMAD and DIRECT8 and NORM_S >= {"tree", "single", "lit", "direct"}   # (VB2 is VKTOP's register: free when every test is scalar)
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
 LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
 
@@ -248,6 +275,7 @@ class Gen:
         # deferred vector instructions (see DEFER): a FIFO of (text, reads_sym, reads_vcc); `reach`: the previous instruction can
         # fall through to the next one; lstate: label -> the queue every path must arrive with (checked at each branch / label)
         self.q = []
+        self.sq = []          # scalar (or index-mode) instructions for the next decision's shadow (SSHADOW): straight-line code only
         self.reach = True
         self.lstate = {}
         self.sec, self.role = "prologue", "book"   # attribution of what is emitted (profiling only)
@@ -277,6 +305,7 @@ class Gen:
         ops = out.replace(",", " ").split()
         op = ops[0]
         if op in ("s_branch", "s_call_b64", "s_setpc_b64") or op.startswith("s_cbranch"):
+            assert not self.sq or kw.get("_normtest"), "a branch while scalar instructions wait for a shadow: " + out
             tgt = re.search(r"L(\w+)%=", out)
             if tgt and op != "s_call_b64":
                 self._edge(tgt.group(1), op != "s_branch")
@@ -293,6 +322,7 @@ class Gen:
             self.reach = False
 
     def lab(self, name):
+        assert not self.sq, "label %s while scalar instructions wait for a shadow" % name
         reg = self.lstate.get(name)
         if self.reach:
             if reg is None:
@@ -350,6 +380,17 @@ class Gen:
             self.e(q[0], _queued=True, _tag=getattr(q, "tag", None))
             k += 1
         return k
+
+    def queue_s(self, fmt, kind="", **kw):
+        """a scalar instruction nothing waits for: into the next decision's shadow (SSHADOW lists the kinds), else here"""
+        if kind not in SSHADOW:
+            return self.e(fmt, **kw)
+        self.sq.append((fmt, kw, (self.sec, self.role)))
+
+    def shadow_s(self):
+        sq, self.sq = self.sq, []
+        for fmt, kw, tag in sq:
+            self.e(fmt, _tag=tag, **kw)
 
     def flush(self):
         while self.q:
@@ -410,14 +451,17 @@ class Gen:
             if not EOFWRAP:
                 self.e("s_cmp_eq_u32 {off}, {lim}")
                 self.e("s_cbranch_scc1 " + self.L("Xeof"))
-            self.e("v_readlane_b32 {n1}, {winb}, {off}")
+            if not NBPRE:
+                self.e("v_readlane_b32 {n1}, {winb}, {off}")
             if NORM64:   # range < 2^24 here: its top byte is zero, so one 64-bit shift of the (range, code) pair moves both
                 self.e("s_lshl_b64 " + RC + ", " + RC + ", 8")
             else:
                 self.e("s_lshl_b32 {range}, {range}, 8")
                 self.e("s_lshl_b32 {code}, {code}, 8")
-            self.e("s_or_b32 {code}, {code}, {n1}")
+            self.e("s_or_b32 {code}, {code}, " + ("{nb}" if NBPRE else "{n1}"))
             self.e("s_add_u32 {off}, {off}, 1")
+            if NBPRE:    # the byte after it, for the next normalisation (a used-up window: garbage, the refill reads again)
+                self.e("v_readlane_b32 {nb}, {winb}, {off}")
             if not OFFBIAS:
                 self.e("s_bitcmp1_b32 {off}, 6")
             self.e("s_cbranch_scc0 " + self.L(ret))
@@ -454,6 +498,7 @@ class Gen:
             self.e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)        # range - bound
             self.shadow(SHADOW)
             self.flush_reads(vcc=True, sym=True)     # (the caller may extend sym right after the decision)
+            self.shadow_s()
             mask()
             self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
@@ -471,10 +516,12 @@ class Gen:
             self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
             self.shadow(SHADOW - 1)
             self.flush_reads(vcc=True, sym=True)
+            self.shadow_s()
             mask()
         else:
             mask()
             self.e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
+            self.shadow_s()
         self.e("s_sub_u32 {sr1}, {range}, {sb}")
         self.e("s_sub_u32 {sc1}, {code}, {sb}")          # SCC = code < bound  <=>  bit == 0
         self.e("s_cselect_b32 {range}, {sb}, {sr1}")
@@ -557,12 +604,14 @@ class Gen:
             e("v_readlane_b32 {sr1}, {vr}, {ln}", ln=ln)             # range - bound
             self.shadow(SHADOW)
             self.flush_reads(sym=True)                               # (sym changes below)
+            self.shadow_s()
             e("s_sub_u32 {sc1}, {code}, {range}")                    # SCC = code < bound  <=>  bit == 0
             e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
             e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
             self.norm(kind="tree")
             return
         self.flush()
+        self.shadow_s()
         e("v_lshrrev_b32 {vt}, 11, {range}")
         e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
         e("s_nop 0")  # gfx940: one wait state between a VALU write and the v_readlane of it (measured: without it every stream decodes wrongly)
@@ -670,10 +719,13 @@ class Gen:
         if not EOFWRAP:
             e("s_cmp_eq_u32 {off}, {lim}")
             e("s_cbranch_scc1 " + L("Xeof"))
-        e("v_readlane_b32 {n1}, {winb}, {off}")
+        if not NBPRE:
+            e("v_readlane_b32 {n1}, {winb}, {off}")
         e("s_lshl_b64 " + RC + ", " + RC + ", 8")
-        e("s_or_b32 {code}, {code}, {n1}")
+        e("s_or_b32 {code}, {code}, " + ("{nb}" if NBPRE else "{n1}"))
         e("s_add_u32 {off}, {off}, 1")
+        if NBPRE:
+            e("v_readlane_b32 {nb}, {winb}, {off}")
         if not OFFBIAS:
             e("s_bitcmp1_b32 {off}, 6")
         e("s_cbranch_scc1 " + L(k))
@@ -711,7 +763,8 @@ class Gen:
             self.e("s_nop 0")
         self.e("v_cndmask_b32_e64 {VT0}, -1, {VT0}, " + MPAIR)
         self.e("buffer_store_byte {pend_val}, {VT0}, {out_rsrc}, 0 offen" + STORE_MOD)
-        self.e("s_mov_b32 {pend_n}, 0")
+        if extract:                                        # (extract=False: a match follows and sets pend_n itself)
+            self.e("s_mov_b32 {pend_n}, 0")
 
     def set_guards(self, t):
         """gtop / gdist from len, lim, target, safe_len, mlen (prologue and window refill; clobbers SCC and t)"""
@@ -758,6 +811,8 @@ class Gen:
             e("v_add_u32 {vb}, -5, {VT1}")                 # n
             e("v_mul_u32_u24 {vt}, (" + L("db_e") + "-" + L("db_s") + "), {vb}")
             e("v_sub_u32 {tbl_b}, " + L("dend0") + "-" + L("base") + ", {vt}")
+            if DISP2:                                      # B2 = offset + n * chain stride (see distance_tables)
+                e("v_mad_u32_u24 {tbl_b}, {vb}, {VCH}, {tbl_b}")
             e("v_lshl_or_b32 {tbl_b}, {tbl_b}, 8, {vb}")
         else:
             e("v_sub_u32 {vt}, 31, {VT1}")                     # 26 - count
@@ -918,13 +973,19 @@ class Gen:
         with self.in_cold():
             self.lab(name)
             e("s_and_b32 {t3}, {row}, 7")                       # the new row's slot
-            e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
-            e("v_lshl_or_b32 {VT1}, {u3}, 16, {u2}")
             e("s_and_b32 {t0}, {cur_row}, 7")
-            e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
-            e("v_mov_b32 " + LIT0 + ", {VT0}")
-            e("v_mov_b32 " + LIT1 + ", {VT1}")
-            e("s_set_gpr_idx_off")
+            if SWAP2:
+                e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
+                e("v_lshl_or_b32 " + LIT0 + ", {u1}, 16, {u0}")
+                e("v_lshl_or_b32 " + LIT1 + ", {u3}, 16, {u2}")
+                e("s_set_gpr_idx_off")
+            else:
+                e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
+                e("v_lshl_or_b32 {VT1}, {u3}, 16, {u2}")
+                e("s_set_gpr_idx_on {t0}, gpr_idx(DST)")
+                e("v_mov_b32 " + LIT0 + ", {VT0}")
+                e("v_mov_b32 " + LIT1 + ", {VT1}")
+                e("s_set_gpr_idx_off")
             e("v_readlane_b32 {t1}, {vtag}, {t3}")              # whose row the slot holds
             e("s_cmp_eq_u32 {t1}, {row}")
             e("s_cbranch_scc1 " + L(k + "hit"))
@@ -950,10 +1011,20 @@ class Gen:
             e("s_set_gpr_idx_off")
             e("s_branch " + L(k + "unpack"))
             self.lab(k + "hit")
-            e("s_set_gpr_idx_on {t3}, gpr_idx(SRC0)")
-            e("v_mov_b32 {VT0}, " + LIT0)
-            e("v_mov_b32 {VT1}, " + LIT1)
-            e("s_set_gpr_idx_off")
+            if SWAP2:
+                e("s_set_gpr_idx_on {t3}, gpr_idx(SRC1)")
+                e("v_and_b32 {u0}, 0xffff, " + LIT0)
+                e("v_lshrrev_b32 {u1}, 16, " + LIT0)
+                e("v_and_b32 {u2}, 0xffff, " + LIT1)
+                e("v_lshrrev_b32 {u3}, 16, " + LIT1)
+                e("s_set_gpr_idx_off")
+                e("s_mov_b32 {cur_row}, {row}")
+                e("s_branch " + self.L(ret))
+            else:
+                e("s_set_gpr_idx_on {t3}, gpr_idx(SRC0)")
+                e("v_mov_b32 {VT0}, " + LIT0)
+                e("v_mov_b32 {VT1}, " + LIT1)
+                e("s_set_gpr_idx_off")
             self.lab(k + "unpack")
             e("v_and_b32 {u0}, 0xffff, {VT0}")
             e("v_lshrrev_b32 {u1}, 16, {VT0}")
@@ -967,6 +1038,21 @@ class Gen:
         if self.hbm:
             return self.row_swap_stub_hbm(name, ret)
         e = self.e
+        if SWAP2 and LITSPLIT:
+            with self.in_cold():
+                self.lab(name)
+                e("s_set_gpr_idx_on {cur_row}, gpr_idx(DST)")       # the walked row, packed, straight into its registers
+                e("v_lshl_or_b32 " + LIT0 + ", {u1}, 16, {u0}")
+                e("v_lshl_or_b32 " + LIT1 + ", {u3}, 16, {u2}")
+                e("s_set_gpr_idx_on {row}, gpr_idx(SRC1)")          # the new one straight out of its own
+                e("v_and_b32 {u0}, 0xffff, " + LIT0)
+                e("v_lshrrev_b32 {u1}, 16, " + LIT0)
+                e("v_and_b32 {u2}, 0xffff, " + LIT1)
+                e("v_lshrrev_b32 {u3}, 16, " + LIT1)
+                e("s_set_gpr_idx_off")
+                e("s_mov_b32 {cur_row}, {row}")
+                e("s_branch " + self.L(ret))
+            return
         with self.in_cold():
             self.lab(name)
             e("v_lshl_or_b32 {VT0}, {u1}, 16, {u0}")
@@ -1106,13 +1192,20 @@ class Gen:
             e("v_writelane_b32 {vtagm}, {row}, m0")              # (the LDS slot itself is written by mrow_store, after the literal)
             e("s_branch " + L("lm_b"))
 
+    def mrow_request(self):
+        """EARLYLDS: the read of mrow_load, issued as soon as `row` is known"""
+        if EARLYLDS and not self.hbm:
+            self.e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
+            self.e("ds_read_b128 " + MROW + ", {VA}")
+
     def mrow_load(self):
         """MROW = the matched sub-tables of literal row `row` (4 dwords per lane)"""
         e, L = self.e, self.L
         if self.hbm:
             return self.mrow_load_hbm()
-        e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
-        e("ds_read_b128 " + MROW + ", {VA}")
+        if not EARLYLDS:
+            e("v_lshl_add_u32 {VA}, {row}, 10, {VL16}")
+            e("ds_read_b128 " + MROW + ", {VA}")
         e("s_waitcnt lgkmcnt(0)")
 
     def mrow_store(self):
@@ -1184,18 +1277,34 @@ class Gen:
         self.tree_walk(V["VPS"], 6, first_lane="1")
         self.tree_update(V["VPS"], 6, defer=True)            # (queued: emitted in the shadows of the align walk; the tree goes
         self.sec = "dist dispatch"
-        e("v_readlane_b32 {t2}, {tbl_a}, {sym}")             #  back to its register once it is complete: posslot_writeback)
-        if DIRECT8:
+        if DISP2:
+            e("s_flbit_i32_b32 {t6}, {range}")               # leading zeros of range: 0..7
+            e("v_add_u32 {VT0}, {t6}, {tbl_b}")              # low byte: n + clz
+            e("v_mad_u32_u24 {VT2}, {t6}, {VCH}, {VB2}")     # B2 + clz * stride
+            e("v_bfe_u32 {VT1}, {VT0}, 3, 5")
+            e("v_mad_i32_i24 {VT0}, {VT1}, {VNDN}, {VT2}")
+            e("s_mov_b32 {t4}, 0")
+            e("v_readlane_b32 {t2}, {tbl_a}, {sym}")
+            e("v_readlane_b32 {t3}, {VT0}, {sym}")
+        else:
+            e("v_readlane_b32 {t2}, {tbl_a}, {sym}")         #  back to its register once it is complete: posslot_writeback)
+        if DISP2:
+            pass
+        elif DIRECT8:
             # entry = offset + ((n + clz) & 7) * chain size - ((n + clz) >> 3) * normalisation size, for every lane
             e("s_flbit_i32_b32 {t6}, {range}")               # leading zeros of range: 0..7
             e("v_add_u32 {VT0}, {t6}, {tbl_b}")
             e("v_and_b32 {VT1}, 7, {VT0}")
             e("v_bfe_u32 {VT2}, {VT0}, 3, 3")
             e("v_lshrrev_b32 {VT0}, 8, {VT0}")
-            e("v_mul_u32_u24 {VT1}, (" + L("dend1") + "-" + L("dend0") + "), {VT1}")
-            e("v_mul_u32_u24 {VT2}, (" + L("dn_e") + "-" + L("dn_s") + "), {VT2}")
-            e("v_add_u32 {VT0}, {VT0}, {VT1}")
-            e("v_sub_u32 {VT0}, {VT0}, {VT2}")
+            if DISPMAD:
+                e("v_mad_u32_u24 {VT0}, {VT1}, {VCH}, {VT0}")
+                e("v_mad_i32_i24 {VT0}, {VT2}, {VNDN}, {VT0}")
+            else:
+                e("v_mul_u32_u24 {VT1}, (" + L("dend1") + "-" + L("dend0") + "), {VT1}")
+                e("v_mul_u32_u24 {VT2}, (" + L("dn_e") + "-" + L("dn_s") + "), {VT2}")
+                e("v_add_u32 {VT0}, {VT0}, {VT1}")
+                e("v_sub_u32 {VT0}, {VT0}, {VT2}")
             e("s_mov_b32 {t4}, 0")
             e("v_readlane_b32 {t3}, {VT0}, {sym}")
         else:
@@ -1235,13 +1344,21 @@ class Gen:
                 self.direct_bit(R("t4"))
         self.sec = "align"
         lab("direct_done")
-        self.tree_walk(R("m_align"), 4, first_lane="1")
-        self.posslot_writeback()
+        written = False
+        for i in range(4):
+            if "wb" in SSHADOW and i == 2 and not self.q:    # (the pos_slot tree's update went into the shadows of levels 0 and 1)
+                with self.at(sec="pos_slot", role="book"):
+                    self.queue_s("s_set_gpr_idx_on {t5}, gpr_idx(DST)", kind="wb")
+                    self.queue_s("v_mov_b32 " + PS0M2 + ", {VPS}", kind="wb")
+                    self.queue_s("s_set_gpr_idx_off", kind="wb")
+                written = True
+            self.bit_nu(R("m_align"), "1" if i == 0 else R("sym"), first=(i == 0))
+        if not written:
+            self.posslot_writeback()
         self.tree_update(R("m_align"), 4)
-        e("s_lshl_b32 {t4}, {t4}, 4")
         e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
         e("s_brev_b32 {t3}, {t3}")                           # a'
-        e("s_add_u32 {t4}, {t4}, {t3}")
+        e("s_lshl4_add_u32 {t4}, {t4}, {t3}")
         e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
         self.sec = "dist slots < 14"
         with self.in_cold():                                 # falls through into `copy`
@@ -1294,6 +1411,12 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        if DISPMAD and DIRECT8:
+            e("v_mov_b32 {VCH}, (" + L("dend1") + "-" + L("dend0") + ")")          # stride of the direct-bit chains
+            e("v_mov_b32 {VNDN}, (" + L("dn_s") + "-" + L("dn_e") + ")")           # minus the size of a normalisation block
+            if DISP2:                                                                 # ... minus (8 strides + a normalisation block)
+                e("v_mov_b32 {VT0}, (" + L("dend0") + "-" + L("dend1") + ")")
+                e("v_lshl_add_u32 {VNDN}, {VT0}, 3, {VNDN}")
         if EOFWRAP:      # from the C++ side's reader (aligned windows, off = lane, EOF at lane lim) to the loop's (undone in finish())
             e("s_cmpk_lt_u32 {lim}, 64")
             e("s_cbranch_scc1 " + L("Oentry_last"))
@@ -1303,6 +1426,8 @@ class Gen:
             e("s_cmpk_lt_u32 {n0}, 63")                      # 1..63 bytes beyond this window: the prefetched window must be the
             e("s_cbranch_scc1 " + L("Oentry_pref"))          # end-aligned one
             lab("entry_ok")
+            if NBPRE:
+                e("v_readlane_b32 {nb}, {winb}, {off}")
             with self.in_cold():
                 lab("Oentry_pref")
                 e("s_add_u32 {n0}, {wbase}, {lim}")
@@ -1340,6 +1465,8 @@ class Gen:
             e("v_cndmask_b32 {VSTT}, {vx}, {VSTT}, vcc")
         self.set_guards(R("n0"))
         self.tables_prologue()
+        if DISP2:
+            e("v_lshrrev_b32 {VB2}, 8, {tbl_b}")
         if PRIO:
             e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD
             if PRIO < 0:
@@ -1369,8 +1496,8 @@ class Gen:
         if STATE_TBL:
             e("v_readlane_b32 {state}, {VSTT}, {state}")     # state after a literal (lzma.rs:472-478)
         else:
-            e("s_sub_u32 {state}, {state}, 3")               # state after a literal (lzma.rs:472-478), states 0..6
-            e("s_max_i32 {state}, {state}, 0")
+            self.queue_s("s_sub_u32 {state}, {state}, 3", kind="state")    # state after a literal (lzma.rs:472-478), states 0..6
+            self.queue_s("s_max_i32 {state}, {state}, 0", kind="state")
         self.tree_walk(R("u0"), 6, first_lane="1")  # nodes 1..63 -> u0
         self.tree_update(R("u0"), 6, defer=True)   # (queued: emitted in the shadows of levels 6 and 7)
         self.literal_tail(False)
@@ -1392,13 +1519,13 @@ class Gen:
             self.taken(R("m_ismatch"))
         self.sec = "is_rep"
         self.decide(R("m_rep"), R("state"), "rep_match")     # is_rep[state]
-        e("s_mov_b32 {rep3}, {rep2}")
-        e("s_mov_b32 {rep2}, {rep1}")
-        e("s_mov_b32 {rep1}, {rep0}")
+        self.queue_s("s_mov_b32 {rep3}, {rep2}", kind="rep")
+        self.queue_s("s_mov_b32 {rep2}, {rep1}", kind="rep")
+        self.queue_s("s_mov_b32 {rep1}, {rep0}", kind="rep")
         self.sec = "length"
         self.len_decode(0, "len0_done")
-        e("s_cmpk_lt_u32 {state}, 7")
-        e("s_cselect_b32 {state}, 7, 10")
+        self.queue_s("s_cmpk_lt_u32 {state}, 7", kind="state")
+        self.queue_s("s_cselect_b32 {state}, 7, 10", kind="state")
         # ---- decode_distance (lzma.rs:563-592)
         self.distance_tables()
 
@@ -1421,18 +1548,24 @@ class Gen:
             self.finish_pending(have_t6=True, prof="m")
         lab("lit_pM")
         self.literal_row("M")
+        self.mrow_request()
         if STATE_TBL:
             e("v_readlane_b32 {state}, {VSTT}, {state}")     # states 7..11 -> 4, 5, 6, 4, 5
         else:
             e("s_cmpk_lt_u32 {state}, 10")                   # states 7..11 -> 4, 5, 6, 4, 5
             e("s_cselect_b32 {t1}, 3, 6")
             e("s_sub_u32 {state}, {state}, {t1}")
-        e("s_add_u32 {t0}, {rep0}, 1")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
-        e("s_cmp_gt_u32 {t0}, {dict_size}")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
-        e("s_cmp_gt_u32 {t0}, {len}")
-        e("s_cbranch_scc1 " + L("Xmatch_dist_out"))
+        if MLGUARD:
+            e("s_cmp_ge_u32 {rep0}, {gdist}")                # gdist <= min(len, dict_size): below it both checks pass
+            e("s_cbranch_scc1 " + L("Omlit_dist"))
+            lab("lm_dist_ok")
+        else:
+            e("s_add_u32 {t0}, {rep0}, 1")
+            e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+            e("s_cmp_gt_u32 {t0}, {dict_size}")
+            e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+            e("s_cmp_gt_u32 {t0}, {len}")
+            e("s_cbranch_scc1 " + L("Xmatch_dist_out"))
         e("s_cmp_eq_u32 {mb}, -1")
         e("s_cbranch_scc1 " + L("Omb_fetch"))
         lab("lm_a")
@@ -1656,6 +1789,8 @@ class Gen:
                 e("s_lshr_b32 {n1}, {len}, %d" % PRIO)       # (n0 / n1: the only temporaries free wherever a refill happens)
                 e("s_add_u32 {n1}, {n1}, {prioph}")
                 self.set_prio(R("n1"), R("n0"))
+            if NBPRE:
+                e("v_readlane_b32 {nb}, {winb}, {off}")
             e("s_setpc_b64 " + RET)
             if EOFWRAP:
                 lab("Orefill_end")
@@ -1668,7 +1803,23 @@ class Gen:
                 e("s_setpc_b64 " + RET)
 
             self.sec = "literal matched"
+            if MLGUARD:
+                lab("Omlit_dist")                             # the exact checks, in the reference's order; then a fresh bound if one is due
+                e("s_add_u32 {t0}, {rep0}, 1")
+                e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+                e("s_cmp_gt_u32 {t0}, {dict_size}")
+                e("s_cbranch_scc1 " + L("Xmatch_dist_dict"))
+                e("s_cmp_gt_u32 {t0}, {len}")
+                e("s_cbranch_scc1 " + L("Xmatch_dist_out"))
+                e("s_cmpk_ge_u32 {mlen}, 64")                 # (gdist = 0 on purpose: the copy of a long match leaves the loop)
+                e("s_cbranch_scc1 " + L("lm_dist_ok"))
+                e("s_cmp_gt_u32 {len}, {safe_len}")           # (... and so does everything near the output limit)
+                e("s_cbranch_scc1 " + L("lm_dist_ok"))
+                e("s_min_u32 {gdist}, {len}, {dict_size}")
+                e("s_branch " + L("lm_dist_ok"))
             lab("Omb_fetch")                                  # lzb.last_n(rep0 + 1)
+            if MLGUARD:
+                e("s_add_u32 {t0}, {rep0}, 1")
             e("s_sub_u32 {t1}, {len}, {t0}")
             e("v_mov_b32 {VT0}, {t1}")
             e("buffer_load_ubyte {VT0}, {VT0}, {out_rsrc}, 0 offen")
