@@ -144,6 +144,14 @@ SSHADOW = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_SSHADOW",
 # after it as its LAST instruction, so that v_readlane's vector -> scalar hop runs under the next decision's vector head instead of in
 # front of the stub's own scalar instructions (micro-benchmark: 80 -> 69 cycles per normalisation at four waves per SIMD).
 NBPRE = os.environ.get("MILZMA_GEN_NBPRE", "1") == "1"
+# LENDEFER (not for 16 position states): the update of a new match's low length tree (the common lengths 2..9) rides in the shadows of the
+# pos_slot walk's first two decisions instead of standing between the two walks (seven vector instructions, five of them dependent).  The
+# rare lengths (mid / high tree) used to join in front of the pos_slot walk; they get their own copy of its first two levels and join behind.
+LENDEFER = os.environ.get("MILZMA_GEN_LENDEFER", "0") == "1"   # (measured, profiles/r04_kernel_ab.txt section 4: nothing -- off)
+# ALIGNLAZY (with LENDEFER's split): nothing follows the align walk that could carry its tree's update in a shadow, so the walk only
+# remembers its final symbol (asym); the update is made in the shadows of the NEXT new match's pos_slot walk (levels 2 and 3) -- the align
+# tree is read nowhere else -- or when the loop is left.  asym = 0: nothing pending (lane 0 of m_align is no node).
+ALIGNLAZY = os.environ.get("MILZMA_GEN_ALIGNLAZY", "0") == "1" and not (WAITPROF or WAITPROF2)   # (the wait profiles use asym's register)
 EARLYLDS = os.environ.get("MILZMA_GEN_EARLYLDS", "1") == "1"
 # MLGUARD: a matched literal's two distance checks (lzma.rs:541-546) behind the match guard gdist (<= min(len, dict_size)): one compare
 # instead of three; the exact checks out of line.
@@ -160,7 +168,7 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         pad="s69", nb="s69", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         pad="s69", nb="s69", asym="s96", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
 DM = "s[90:91]"     # lane mask of a deferred tree update (the constants 2017 / 2048 that used to live there are VGPRs now)
@@ -664,6 +672,20 @@ class Gen:
             e("s_and_b64 vcc, vcc, " + MPAIR)
         e("v_cndmask_b32 {T}, {T}, {vt}, vcc", T=T)
 
+    @role("update")
+    def align_pending(self, queued):
+        """the align tree's update from asym (ALIGNLAZY); queued: into the coming shadows, else here"""
+        put = self.defer if queued else (lambda fmt, **kw: self.e(fmt, **{k: v for k, v in kw.items() if k not in ("reads_sym", "reads_vcc")}))
+        T = R("m_align")
+        put("v_lshrrev_b32 {DVA}, {sh}, {asym}", sh=R("VSH4"))
+        put("v_bfe_u32 {DVX}, {asym}, {sh}, 1", sh=R("VSH4M1"))
+        put("v_cmp_eq_u32_e64 " + DM + ", {DVA}, {v_lane}")
+        put("v_mad_u32_u24 {DVX}, {DVX}, {c2017}, 31")
+        put("v_mad_u32_u24 {DVA}, {T}, 31, {DVX}", T=T)
+        put("v_lshrrev_b32 {DVA}, 5, {DVA}")
+        put("v_cndmask_b32_e64 {T}, {T}, {DVA}, " + DM, T=T)
+        put("s_mov_b32 {asym}, 0")
+
     @role("core")
     def decide(self, T, ln, taken, cmp_lane=None, defer=True):
         """a decision that ends in a branch: falls through for a 0 bit, jumps to `taken` for a 1 bit.
@@ -877,7 +899,7 @@ class Gen:
         self.e("s_branch " + self.L("finish"))
 
     # ---- LenDecoder::decode ------------------------------------------------------------------------------
-    def len_tree3(self, reg, reg_b, tag):
+    def len_tree3(self, reg, reg_b, tag, defer=False):
         """the 3-bit tree low[pos_state] / mid[pos_state]; leaves the inverted path in sym's low 3 bits.
         4 position states: roots at lanes 4 + ps of `reg` (heap-numbered to lane 31).  16 (pb4): roots at lanes
         8 + (ps & 7) of `reg` / `reg_b` by ps bit 3 (heap-numbered to lane 63)."""
@@ -885,7 +907,7 @@ class Gen:
         if not self.pb4:
             e("s_add_u32 {sym}, {ps}, 4")
             self.tree_walk(R(reg), 3)
-            self.tree_update(R(reg), 5)
+            self.tree_update(R(reg), 5, defer=defer)
             return
         join = self.new("LT")
         e("s_bitcmp1_b32 {ps}, 3")
@@ -901,17 +923,19 @@ class Gen:
             self.tree_update(R(reg_b), 6)
             e("s_branch " + L(join))
 
-    def len_decode(self, which, done):
-        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (the match length) in mlen; jumps to `done`."""
+    def len_decode(self, which, done, defer_low=False):
+        """which: 0 = len_decoder, 1 = rep_len_decoder.  Result (the match length) in mlen; jumps to `done`.
+        defer_low: the low tree's update stays queued and `done` is NOT placed here (the caller places it, out of line)."""
         p = "m_len" if which == 0 else "m_rlen"
         w = "l%d" % which
         choice, choice2 = str(48 + 2 * which), str(49 + 2 * which)
         CH = R("m_rep") if self.pb4 else R("m_ismatch")   # (pb4: is_match fills its registers; m_rep's lanes 48..51 are free)
         self.decide(CH, choice, w + "_nlow")
-        self.len_tree3(p + "_low", p + "_low_b", w + "lo")
+        self.len_tree3(p + "_low", p + "_low_b", w + "lo", defer=defer_low)
         self.e("s_and_b32 {t0}, {sym}, 7")                # length = 2 + path = 9 - inverted path
         self.e("s_sub_u32 {mlen}, 9, {t0}")
-        self.lab(done)                                    # the common (short) lengths fall through
+        if not defer_low:
+            self.lab(done)                                # the common (short) lengths fall through
         with self.in_cold():
             self.lab(w + "_nlow")
             self.taken(CH)
@@ -1265,16 +1289,27 @@ class Gen:
             self.e("v_mov_b32 " + PS0M2 + ", {VPS}")
             self.e("s_set_gpr_idx_off")
 
-    def distance_tables(self):
-        """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
-        for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
-        e, lab, L = self.e, self.lab, self.L
-        self.sec = "pos_slot"
+    def posslot_head(self):
+        """the walked pos_slot tree into VPS, the walk's first two levels"""
+        e = self.e
         e("s_min_u32 {t5}, {mlen}, 5")                      # len_state + 2  (gfx9 has no v_movrel*: s_set_gpr_idx)
         e("s_set_gpr_idx_on {t5}, gpr_idx(SRC0)")
         e("v_mov_b32 {VPS}, " + PS0M2)
         e("s_set_gpr_idx_off")
-        self.tree_walk(V["VPS"], 6, first_lane="1")
+        self.bit_nu(V["VPS"], "1", first=True)
+        self.bit_nu(V["VPS"], R("sym"))
+
+    def distance_tables(self, split_head=False):
+        """decode_distance (lzma.rs:563-592): pos_slot tree of len_state, then by table (tables_prologue) to the code
+        for this slot.  rep0 = tbl_a - ((d' << 4) + a') for slots >= 14 (d', a': the inverted direct / align bits)."""
+        e, lab, L = self.e, self.lab, self.L
+        self.sec = "pos_slot"
+        if not split_head:
+            self.posslot_head()
+        else:                                               # (the caller emitted the head, twice, and the label behind it)
+            pass
+        for i in range(2, 6):
+            self.bit_nu(V["VPS"], R("sym"))
         self.tree_update(V["VPS"], 6, defer=True)            # (queued: emitted in the shadows of the align walk; the tree goes
         self.sec = "dist dispatch"
         if DISP2:
@@ -1355,7 +1390,11 @@ class Gen:
             self.bit_nu(R("m_align"), "1" if i == 0 else R("sym"), first=(i == 0))
         if not written:
             self.posslot_writeback()
-        self.tree_update(R("m_align"), 4)
+        if getattr(self, "lazy", False):
+            with self.at(role="update"):
+                e("s_mov_b32 {asym}, {sym}")
+        else:
+            self.tree_update(R("m_align"), 4)
         e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
         e("s_brev_b32 {t3}, {t3}")                           # a'
         e("s_lshl4_add_u32 {t4}, {t4}, {t3}")
@@ -1411,6 +1450,7 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        e("s_mov_b32 {asym}, 0")
         if DISPMAD and DIRECT8:
             e("v_mov_b32 {VCH}, (" + L("dend1") + "-" + L("dend0") + ")")          # stride of the direct-bit chains
             e("v_mov_b32 {VNDN}, (" + L("dn_s") + "-" + L("dn_e") + ")")           # minus the size of a normalisation block
@@ -1523,11 +1563,31 @@ class Gen:
         self.queue_s("s_mov_b32 {rep2}, {rep1}", kind="rep")
         self.queue_s("s_mov_b32 {rep1}, {rep0}", kind="rep")
         self.sec = "length"
-        self.len_decode(0, "len0_done")
-        self.queue_s("s_cmpk_lt_u32 {state}, 7", kind="state")
-        self.queue_s("s_cselect_b32 {state}, 7, 10", kind="state")
+        split = LENDEFER and not self.pb4 and "tree" in DEFER and "tree" in FORMB
+        self.len_decode(0, "len0_done", defer_low=split)
+        for cold in ((False, True) if split else (False,)):
+            ctx = self.in_cold() if cold else None
+            if ctx:
+                ctx.__enter__()
+                self.sec = "length"
+                lab("len0_done")                            # the rare lengths: nothing queued; their own copy of the walk's head
+            self.queue_s("s_cmpk_lt_u32 {state}, 7", kind="state")
+            self.queue_s("s_cselect_b32 {state}, 7, 10", kind="state")
+            if split:
+                self.sec = "pos_slot"
+                self.posslot_head()
+            if ctx:
+                e("s_branch " + L("ps_l2"))
+                ctx.__exit__()
+        self.lazy = split and ALIGNLAZY
+        if split:
+            assert not self.q, "the low length tree's update did not fit the shadows of the pos_slot walk's head"
+            lab("ps_l2")
+            if self.lazy:
+                with self.at(sec="align"):
+                    self.align_pending(True)
         # ---- decode_distance (lzma.rs:563-592)
-        self.distance_tables()
+        self.distance_tables(split_head=split)
 
         # ================= LZ copy, short and unclipped (lzbuffer.rs:255-281) =================
         self.sec = "copy"
@@ -1772,9 +1832,9 @@ class Gen:
                     e("s_cbranch_scc1 " + L("rot"))
                     e("s_and_b32 {n1}, {wbase}, 0x3c0")
                     e("s_cbranch_scc1 " + L("norot"))
-                    e("s_load_dword {clk_t}, {flagptr}, 0x0 glc")
+                    e("s_load_dword {n1}, {flagptr}, 0x0 glc")     # (n1: free again after the test above; s96 holds asym)
                     e("s_waitcnt lgkmcnt(0)")
-                    e("s_cmp_eq_u32 {clk_t}, 0")
+                    e("s_cmp_eq_u32 {n1}, 0")
                     e("s_cbranch_scc1 " + L("norot"))
                     e("s_bitset1_b32 {prioph}, 8")
                     lab("rot")
@@ -1842,6 +1902,8 @@ class Gen:
         # common exit: complete the pending match so that the C++ side sees memory and prev/mb up to date
         e, lab, L = self.e, self.lab, self.L
         lab("finish")
+        if getattr(self, "lazy", False):
+            self.align_pending(False)
         e("s_cmp_eq_u32 {pend_n}, 0")
         e("s_cbranch_scc1 " + L("finish2"))
         e("s_cmpk_ge_u32 {pend_n}, 0x%x" % PEND_UNKNOWN)
