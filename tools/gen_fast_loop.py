@@ -283,6 +283,8 @@ class Gen:
         # deferred vector instructions (see DEFER): a FIFO of (text, reads_sym, reads_vcc); `reach`: the previous instruction can
         # fall through to the next one; lstate: label -> the queue every path must arrive with (checked at each branch / label)
         self.q = []
+        self.split = LENDEFER and not pb4 and "tree" in DEFER and "tree" in FORMB
+        self.lazy = self.split and ALIGNLAZY
         self.sq = []          # scalar (or index-mode) instructions for the next decision's shadow (SSHADOW): straight-line code only
         self.reach = True
         self.lstate = {}
@@ -1390,7 +1392,7 @@ class Gen:
             self.bit_nu(R("m_align"), "1" if i == 0 else R("sym"), first=(i == 0))
         if not written:
             self.posslot_writeback()
-        if getattr(self, "lazy", False):
+        if self.lazy:
             with self.at(role="update"):
                 e("s_mov_b32 {asym}, {sym}")
         else:
@@ -1450,7 +1452,8 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
-        e("s_mov_b32 {asym}, 0")
+        if self.lazy:
+            e("s_mov_b32 {asym}, 0")
         if DISPMAD and DIRECT8:
             e("v_mov_b32 {VCH}, (" + L("dend1") + "-" + L("dend0") + ")")          # stride of the direct-bit chains
             e("v_mov_b32 {VNDN}, (" + L("dn_s") + "-" + L("dn_e") + ")")           # minus the size of a normalisation block
@@ -1563,7 +1566,7 @@ class Gen:
         self.queue_s("s_mov_b32 {rep2}, {rep1}", kind="rep")
         self.queue_s("s_mov_b32 {rep1}, {rep0}", kind="rep")
         self.sec = "length"
-        split = LENDEFER and not self.pb4 and "tree" in DEFER and "tree" in FORMB
+        split = self.split
         self.len_decode(0, "len0_done", defer_low=split)
         for cold in ((False, True) if split else (False,)):
             ctx = self.in_cold() if cold else None
@@ -1579,7 +1582,6 @@ class Gen:
             if ctx:
                 e("s_branch " + L("ps_l2"))
                 ctx.__exit__()
-        self.lazy = split and ALIGNLAZY
         if split:
             assert not self.q, "the low length tree's update did not fit the shadows of the pos_slot walk's head"
             lab("ps_l2")
@@ -1902,7 +1904,7 @@ class Gen:
         # common exit: complete the pending match so that the C++ side sees memory and prev/mb up to date
         e, lab, L = self.e, self.lab, self.L
         lab("finish")
-        if getattr(self, "lazy", False):
+        if self.lazy:
             self.align_pending(False)
         e("s_cmp_eq_u32 {pend_n}, 0")
         e("s_cbranch_scc1 " + L("finish2"))
