@@ -60,7 +60,19 @@ def one_call(label):
         kms = lib.milzma_last_kernel_ms(ctx._h, ctypes.byref(launches))
         print("%s, run %d: %d files, %d ok, %.2f GiB out in %.3f s = %.2f GB/s (the context's last decode call: kernel %.1f ms, %d launches)" %
               (label, rep, n, ok, total / 2**30, dt, total / dt / 1e9, kms, launches.value))
-        if rep == 0:
+        if os.environ.get("BATCH_VERIFY_ALL"):   # every file of every run against its plaintext's CRC-32 (16 host threads)
+            import zlib
+            want = [zlib.crc32(made[k][1]) for k in range(distinct)] if rep == 0 else want_crc
+            globals()["want_crc"] = want
+
+            def crc_of(k):
+                return zlib.crc32((ctypes.c_char * outs[k].len).from_address(ctypes.cast(outs[k].data, ctypes.c_void_p).value)) if outs[k].len else 0
+            with ThreadPoolExecutor(16) as ex:
+                got = list(ex.map(crc_of, range(n)))
+            bad = [k for k in range(n) if outs[k].kind != 0 or outs[k].len != len(made[k % distinct][1]) or got[k] != want[k % distinct]]
+            print("   verified all %d files: %d bad%s" % (n, len(bad), (" (first: %d)" % bad[0]) if bad else ""))
+            assert not bad
+        elif rep == 0:
             for k in (0, n // 2, n - 1):
                 assert ctypes.string_at(outs[k].data, outs[k].len) == made[k % distinct][1], "file %d differs from its plaintext" % k
         for i in range(n):
