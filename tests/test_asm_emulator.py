@@ -227,3 +227,40 @@ def test_emulated_hbm_variant_lclp_above_four():
                 assert r["out"][:len(ref.out)] == ref.out
     finally:
         emu.close()
+
+
+_KNOB_SCRIPT = r"""
+import os, struct, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tools", "emu")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import asmprog, oracle_py as orc
+from lzma_rs_amd import workloads as W
+loops = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False)}
+for kind, lp, known in (("text", 0, True), ("text", 1, False), ("random", 0, True), ("repeat", 0, False)):
+    plain = W.make_plain(kind, 150000, seed=11)
+    lc = 3 - lp                                                  # (lc + lp <= 3: the LP0 / GEN variants' classes)
+    comp = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=2, known_size=known)
+    ref = orc.lzma_decompress(comp)
+    for quantum in (None, 3000):
+        r = loops[lp == 0].decode_raw(comp[13:], lc, lp, 2, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300, quantum=quantum)
+        assert r["status"] == "OK" and r["out"] == plain and r["in_consumed"] + 13 == ref.in_consumed, (kind, lp, known, quantum)
+    cut = comp[:len(comp) // 2]
+    ref = orc.lzma_decompress(cut)
+    r = loops[lp == 0].decode_raw(cut[13:], lc, lp, 2, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300)
+    assert r["status"] == "INPUT_EOF" and r["in_consumed"] + 13 == ref.in_consumed and r["out"][:len(ref.out)] == ref.out
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("knobs", [
+    {"MILZMA_GEN_SSHADOW": "state,rep,wb"}, {"MILZMA_GEN_LENDEFER": "1"}, {"MILZMA_GEN_LENDEFER": "1", "MILZMA_GEN_ALIGNLAZY": "1"},
+    {"MILZMA_GEN_R11S": "tree"}, {"MILZMA_GEN_SWAP2": "0", "MILZMA_GEN_DISPMAD": "0", "MILZMA_GEN_MLGUARD": "0", "MILZMA_GEN_EARLYLDS": "0",
+                                  "MILZMA_GEN_NBPRE": "0"}], ids=lambda k: "+".join(sorted(x[11:] for x in k)))
+def test_emulated_loop_under_measured_and_rejected_knobs(knobs):
+    """The generator switches of round 4's A/Bs (profiles/r04_kernel_ab.txt sections 3-4: scalar bookkeeping in shadows, the two deferred
+    tree updates, range >> 11 on the scalar ALU; and the loop WITHOUT the batch that shipped) still generate loops that decode bit-exactly:
+    what the profile says was measured can be rebuilt and measured again.  (The generator reads its switches at import: a process each.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_GEN_")}
+    env.update(knobs)
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
