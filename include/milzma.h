@@ -311,8 +311,9 @@ int milzma_multi_decode_units(milzma_multi *m, const milzma_unit *units, uint32_
  * output is wanted there too (d_in / d_out: device pointers on that device; descriptors and slack rules as for milzma_decode_units).
  * The units are partitioned over all devices by compressed bytes; the root's share is decoded in place, every other share is packed,
  * sent to its device with one device-to-device copy (the direct xGMI link where the GPUs have peer access; no host memory, no
- * collective), decoded there, and its output comes back the same way into the slices the descriptors name.  All devices work
- * concurrently.  The call works on streams of its own and does not order itself behind work the caller has queued on other
+ * collective) and decoded there; its output reaches the slices the descriptors name either from the decoding waves themselves (a
+ * device with peer access to the root writes every unit's output there while it decodes) or by one device-to-device copy behind
+ * the decode (MILZMA_ROOTED_STREAM=0 forces the copy).  All devices work concurrently.  The call works on streams of its own and does not order itself behind work the caller has queued on other
  * streams: d_in must be complete (and d_out free to be written) when it is made.  results[i]: as from milzma_decode_units.
  * milzma_multi_last_transfer_ms: the slowest device's copy in, the slowest
  * decode, and the slowest copy back plus the placement on the root, of the most recent such call (wall-clock ms). */

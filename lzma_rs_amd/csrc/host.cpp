@@ -213,13 +213,49 @@ void parallel_for(size_t n, F fn) {
     for (size_t i = 0; i < n; i++) fn(i);
     return;
   }
+  // (a thread that cannot be started -- std::system_error -- must not take the process down through the vector's destructor while
+  //  its siblings run: its stride is done here, the ones that did start are joined)
   std::vector<std::thread> pool;
-  for (unsigned k = 0; k < t; k++)
-    pool.emplace_back([=] {
+  try {
+    pool.reserve(t);
+  } catch (const std::bad_alloc&) {
+    for (size_t i = 0; i < n; i++) fn(i);
+    return;
+  }
+  for (unsigned k = 0; k < t; k++) {
+    try {
+      pool.emplace_back([=] {
+        for (size_t i = k; i < n; i += t) fn(i);
+      });
+    } catch (const std::exception&) {
       for (size_t i = k; i < n; i += t) fn(i);
-    });
+    }
+  }
   for (auto& th : pool) th.join();
 }
+
+// result buffers taken from the pool and not yet handed to the caller: back to the pool when the scope is left, however it is left
+// (drop() nulls what it frees: a pooled buffer may be somebody else's a moment later)
+struct HeldBufs {
+  std::vector<uint8_t*> v;
+  void drop() {
+    for (uint8_t*& b : v) {
+      if (b) milzma_free(b);
+      b = nullptr;
+    }
+  }
+  ~HeldBufs() { drop(); }
+};
+
+// joins a helper thread when the scope is left, however it is left (a joinable std::thread's destructor is std::terminate)
+struct JoinOnExit {
+  std::thread& th;
+  std::atomic<bool>& stop;
+  ~JoinOnExit() {
+    stop.store(true, std::memory_order_release);
+    if (th.joinable()) th.join();
+  }
+};
 
 // A large device -> pinned-host copy cut in chunks with an event behind each, so that host threads can start on the
 // front of the buffer while the back is still crossing PCIe (and the mirror image for host -> device).
@@ -1175,6 +1211,10 @@ extern "C" int milzma_crc_units(milzma_ctx* ctx, const milzma_unit* units, uint3
 static int move_units_impl(milzma_ctx* ctx, uint32_t n, const void* d_src, const uint64_t* src_off, void* d_dst, const uint64_t* dst_off,
                            const uint64_t* len, hipStream_t stream) {
   if (!ctx) return MILZMA_INFRA_ERROR;
+  if (ctx->pending) {  // (the move list shares a device buffer with the batch's order array)
+    ctx->err = "a batch is in flight on this context: call milzma_decode_units_wait first";
+    return MILZMA_INFRA_ERROR;
+  }
   if (n == 0) return MILZMA_OK;
   if (!d_src || !d_dst || !src_off || !dst_off || !len) {
     ctx->err = "null argument";
@@ -1705,7 +1745,9 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     // The files' result buffers come page-locked from the pool: the waves write every span straight into the buffer the caller will
     // get (kernels.h: host_ptrs) and the host copies nothing.  If page-locked memory cannot be had, ordinary buffers are filled from
     // the page-locked staging buffer by a host thread, span by span.
-    std::vector<uint8_t*> bufs(nu, nullptr);
+    HeldBufs held;
+    held.v.assign(nu, nullptr);
+    std::vector<uint8_t*>& bufs = held.v;
     std::atomic<int> alloc_failed{0};
     bool direct = pinned_results_wanted();
     if (direct) {
@@ -1714,10 +1756,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         if (!bufs[k]) alloc_failed = 1;
       });
       if (alloc_failed) {
-        for (uint8_t*& b : bufs) {
-          milzma_free(b);
-          b = nullptr;
-        }
+        held.drop();
         alloc_failed = 0;
         direct = false;
       }
@@ -1775,7 +1814,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       trace_mark(ctx, "streamed: input complete");
       if (!input_up) {
         if (ok) (void)milzma_decode_units_wait_impl(ctx, res.data());
-        for (uint8_t* b : bufs) milzma_free(b);
+        held.drop();
         give_up(active);
         finish_alone();
         return MILZMA_INFRA_ERROR;
@@ -1796,12 +1835,14 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
           });
         }
       });
-      const int wr = milzma_decode_units_wait_impl(ctx, res.data());
-      kernel_done.store(true, std::memory_order_release);
-      consumer.join();
+      int wr;
+      {
+        JoinOnExit joined{consumer, kernel_done};
+        wr = milzma_decode_units_wait_impl(ctx, res.data());
+      }
       trace_mark(ctx, "streamed decode + hand-over: done");
       if (wr != MILZMA_OK) {
-        for (uint8_t* b : bufs) milzma_free(b);
+        held.drop();
         give_up(active);
         finish_alone();
         return MILZMA_INFRA_ERROR;
@@ -1825,7 +1866,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
           bufs[k] = nullptr;
         }
       }
-      for (uint8_t* b : bufs) milzma_free(b);
+      held.drop();
       size_t ob = 0;
       if (!parked.empty() && !regrow_parked(ctx, units, res, parked, work_stream(ctx), &ob)) {
         give_up(parked);
@@ -1840,7 +1881,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
       // not to be had (no mapped memory, or the launch could not be time-sliced): the batch in flight, if any, is collected and the
       // classic rounds below do the work -- nothing has been handed over yet
       if (ok) (void)milzma_decode_units_wait_impl(ctx, res.data());
-      for (uint8_t* b : bufs) milzma_free(b);
+      held.drop();
       if (!input_up && !upload()) return fail_all();  // (whatever part of the input went up: all of it now)
     }
   }
@@ -2085,6 +2126,9 @@ struct OutBuf {
   // (in `keep`) until this object goes, so that those pointers stay good
   bool hold_first = false;
   uint8_t* keep = nullptr;
+  OutBuf() = default;
+  OutBuf(const OutBuf&) = delete;             // (owns its buffers)
+  OutBuf& operator=(const OutBuf&) = delete;
   ~OutBuf() {
     milzma_free(p);
     milzma_free(keep);
@@ -2601,9 +2645,11 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
                 });
               }
             });
-            const int wr = milzma_decode_units_wait_impl(ctx, res.data());
-            kernel_done.store(true, std::memory_order_release);
-            consumer.join();
+            int wr;
+            {
+              JoinOnExit joined{consumer, kernel_done};
+              wr = milzma_decode_units_wait_impl(ctx, res.data());
+            }
             trace_mark(ctx, "streamed decode + placement: done");
             if (wr != MILZMA_OK) return false;
             streamed_done = true;
@@ -2741,15 +2787,28 @@ static inline void begin_call(milzma_ctx* ctx) {
   if (ctx) ctx->err.clear();
 }
 
+// A host exception (std::bad_alloc) in the middle of a unit-level call: copies and kernels may already be queued and still read the
+// descriptors, the staging and the caller's buffers -- the device is drained before the batch is declared gone and the caller told.
+static int unit_call_threw(milzma_ctx* ctx, const std::exception& e) {
+  if (ctx) {
+    if (ctx->pending) {
+      (void)hipSetDevice(ctx->device);
+      (void)hipDeviceSynchronize();
+    }
+    ctx->pending = false;
+    ctx->ev_used = 0;
+    ctx->err = std::string("host exception: ") + e.what();
+  }
+  return MILZMA_INFRA_ERROR;
+}
+
 extern "C" int milzma_decode_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_in,
                                    void* d_out, milzma_result* results, void* hip_stream) {
   begin_call(ctx);
   try {
     return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream);
   } catch (const std::exception& e) {  // (std::bad_alloc from a staging vector: never let it cross the C ABI)
-    if (ctx) ctx->pending = false;
-    if (ctx) ctx->err = std::string("host exception: ") + e.what();
-    return MILZMA_INFRA_ERROR;
+    return unit_call_threw(ctx, e);
   }
 }
 
@@ -2763,9 +2822,7 @@ extern "C" int milzma_decode_units_ex(milzma_ctx* ctx, const milzma_unit* units,
     }
     return milzma_decode_units_impl(ctx, units, n, d_in, d_out, results, hip_stream, flags);
   } catch (const std::exception& e) {
-    if (ctx) ctx->pending = false;
-    if (ctx) ctx->err = std::string("host exception: ") + e.what();
-    return MILZMA_INFRA_ERROR;
+    return unit_call_threw(ctx, e);
   }
 }
 
@@ -3073,20 +3130,15 @@ extern "C" int milzma_decode_units_async(milzma_ctx* ctx, const milzma_unit* uni
   try {
     return milzma_decode_units_async_impl(ctx, units, n, d_in, d_out, hip_stream);
   } catch (const std::exception& e) {
-    if (ctx) {
-      ctx->pending = false;
-      ctx->err = std::string("host exception: ") + e.what();
-    }
-    return MILZMA_INFRA_ERROR;
+    return unit_call_threw(ctx, e);
   }
 }
 
 extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results) {
   try {
     return milzma_decode_units_wait_impl(ctx, results);
-  } catch (const std::exception& e) {
-    if (ctx) ctx->err = std::string("host exception: ") + e.what();
-    return MILZMA_INFRA_ERROR;
+  } catch (const std::exception& e) {   // (the promotion rounds' staging; the batch is over either way)
+    return unit_call_threw(ctx, e);
   }
 }
 
@@ -3192,6 +3244,7 @@ int multi_file_batch(milzma_multi* m, uint32_t n, const uint8_t* const* ins, con
     multi_outs_fail(n, outs, nullptr, "no multi-device handle");
     return MILZMA_INFRA_ERROR;
   }
+  m->err.clear();
   if (n == 0) return MILZMA_OK;
   if (!ins || !in_lens || !outs) {
     multi_outs_fail(n, outs, nullptr, "null argument");
@@ -3327,6 +3380,7 @@ extern "C" float milzma_multi_last_kernel_ms(const milzma_multi* m, uint32_t k, 
 extern "C" int milzma_multi_decode_units(milzma_multi* m, const milzma_unit* units, uint32_t n, const uint32_t* device_of,
                                          const void* const* d_in, void* const* d_out, milzma_result* results) {
   if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  m->err.clear();   // (what milzma_multi_last_error returns afterwards belongs to THIS call)
   try {
     if (n == 0) return MILZMA_OK;
     if (!units || !device_of || !d_in || !d_out || !results) return multi_fail(m, "null argument");
@@ -3371,6 +3425,7 @@ extern "C" int milzma_multi_decode_units(milzma_multi* m, const milzma_unit* uni
 extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, const milzma_unit* units, uint32_t n, const void* d_in,
                                                 void* d_out, milzma_result* results) {
   if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  m->err.clear();
   try {
     using clk = std::chrono::steady_clock;
     const auto ms_since = [](clk::time_point t0) { return std::chrono::duration<float, std::milli>(clk::now() - t0).count(); };
@@ -3428,8 +3483,16 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
     const auto t_scatter = clk::now();
     if (!so.empty() && move_units_impl(rc, uint32_t(so.size()), d_in, so.data(), m->stage_in.p, dof.data(), ln.data(), work_stream(rc)) != MILZMA_OK)
       return multi_fail(m, rc->err);
-    // 2. every device: its share in, decode, its output back
+    const float pack_ms = so.empty() ? 0.f : ms_since(t_scatter);
+    // 2. every device: its share in, decode, its output back.  The way back is the waves' own where it can be: a device whose share
+    //    is all in the fast kernel's class and that can reach the root's memory (peer access) runs its share as ONE streamed launch
+    //     whose per-unit destinations are the caller's slices on the root -- every 64 KiB span crosses xGMI while the
+    //    unit is still being decoded, nothing is left to gather when the kernel ends (equal streams end together: a copy behind the
+    //    kernel could overlap nothing).  Otherwise (other classes, no peer access, a promoted LZMA2 unit, MILZMA_ROOTED_STREAM=0): one
+    //    peer copy into the root's staging behind the decode, placed by the move kernel below.
+    static const bool stream_back = !(getenv("MILZMA_ROOTED_STREAM") && !strcmp(getenv("MILZMA_ROOTED_STREAM"), "0"));
     std::vector<int> rcode(nd, MILZMA_OK);
+    std::vector<uint8_t> wrote_home(nd, 0);
     std::vector<float> t_in(nd, 0.f), t_dec(nd, 0.f), t_out(nd, 0.f);
     std::vector<std::vector<milzma_result>> res(nd);
     per_device(
@@ -3457,10 +3520,53 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
                       "device-to-device scatter"))
             return bad();
           t_in[k] = ms_since(t0);
+          bool direct = stream_back && c->use_fast;
+          uint64_t max_cap = 0;
+          for (const milzma_unit& u : sub[k]) {
+            direct = direct && classify(c, u) == kFast;
+            max_cap = std::max<uint64_t>(max_cap, u.out_cap);
+          }
+          if (direct && c->device != rc->device) {
+            int can = 0;
+            direct = hipDeviceCanAccessPeer(&can, c->device, rc->device) == hipSuccess && can != 0;
+            if (direct) {
+              const hipError_t pe = hipDeviceEnablePeerAccess(rc->device, 0);
+              direct = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void)hipGetLastError();
+          }
+          if (direct && ensure_progress(c)) {
+            size_t span = size_t(64) << 10;
+            while ((size_t(max_cap) + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
+            std::vector<uint64_t> ptrs(share[k].size() * 2);
+            for (size_t j = 0; j < share[k].size(); j++) {
+              const milzma_unit& u = units[share[k][j]];
+              ptrs[2 * j] = uint64_t(reinterpret_cast<uintptr_t>(static_cast<uint8_t*>(d_out) + u.out_off));
+              ptrs[2 * j + 1] = u.out_cap;
+            }
+            direct = span <= 0x80000000u && upload_host_ptrs(c, ptrs, work_stream(c));
+            if (direct) {
+              c->stream_span = uint32_t(span);
+              c->stream_spans = uint32_t((size_t(max_cap) + 2 * span - 1) / span);
+              c->stream_host = nullptr;
+              c->stream_ptrs = static_cast<const uint64_t*>(c->hostptrs.p);
+              c->stream_in_host = false;
+            }
+          } else {
+            direct = false;
+          }
           t0 = clk::now();
-          if (milzma_decode_units(c, sub[k].data(), uint32_t(sub[k].size()), c->in.p, c->out.p, res[k].data(), work_stream(c)) != MILZMA_OK)
-            return bad();
+          const int dr = milzma_decode_units(c, sub[k].data(), uint32_t(sub[k].size()), c->in.p, c->out.p, res[k].data(), work_stream(c));
+          c->stream_span = c->stream_spans = 0;
+          c->stream_ptrs = nullptr;
+          if (dr != MILZMA_OK) return bad();
           t_dec[k] = ms_since(t0);
+          // (one launch, and it was the streamed one: every unit's bytes are at home.  A promoted unit ran again in a launch of its
+          //  own, without destinations: then the whole share takes the copy.)
+          if (direct && c->stream_active && c->last_launches == 1) {
+            wrote_home[k] = 1;
+            return;
+          }
           t0 = clk::now();
           if (!hip_ok(c, hipMemcpyPeer(static_cast<uint8_t*>(m->stage_out.p) + out_base[k], rc->device, c->out.p, c->device, out_bytes[k]),
                       "device-to-device gather"))
@@ -3482,7 +3588,7 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
       for (size_t j = 0; j < share[k].size(); j++) {
         const uint32_t i = share[k][j];
         results[i] = res[k][j];
-        if (k == root) continue;
+        if (k == root || wrote_home[k]) continue;
         so.push_back(out_base[k] + sub[k][j].out_off);
         dof.push_back(units[i].out_off);
         ln.push_back(std::min<uint64_t>(res[k][j].out_len, units[i].out_cap));
@@ -3497,8 +3603,7 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
       out_max = std::max(out_max, t_out[k]);
       dec_max = std::max(dec_max, t_dec[k]);
     }
-    (void)t_scatter;
-    m->scatter_ms = in_max;       // the slowest device's copy in (the packing on the root runs before the threads start: included below)
+    m->scatter_ms = pack_ms + in_max;   // the packing on the root + the slowest device's copy in
     m->decode_ms = dec_max;
     m->gather_ms = out_max + place_ms;
     return MILZMA_OK;
@@ -3516,6 +3621,7 @@ extern "C" void milzma_multi_last_transfer_ms(const milzma_multi* m, float* scat
 extern "C" int milzma_multi_decode_units_host(milzma_multi* m, const milzma_unit* units, uint32_t n, const void* h_in, size_t in_bytes,
                                               void* h_out, size_t out_bytes, milzma_result* results) {
   if (!m || m->ctx.empty()) return MILZMA_INFRA_ERROR;
+  m->err.clear();
   try {
     if (n == 0) return MILZMA_OK;
     if (!units || !results || (in_bytes && !h_in) || (out_bytes && !h_out)) return multi_fail(m, "null argument");
