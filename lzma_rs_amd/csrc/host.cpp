@@ -72,6 +72,9 @@ struct milzma_ctx {
   uint8_t* pend_out = nullptr;
   std::vector<milzma_unit> pend_units;  // (the caller's array need not outlive the call)
   uint32_t pend_flags = 0;              // MILZMA_DECODE_* of the batch in flight
+  // units of the last batch that were decoded AGAIN in another launch class (an LZMA2 chunk switched to properties outside its
+  // class's reach): a streamed launch's host destinations hold only what the FIRST launch wrote -- whoever streamed fetches these
+  std::vector<uint32_t> promoted;
   // growable output (milzma_decode_units_ex): the last GROW / RESUME call left units parked in slice_ctx (indexed by unit: the next
   // call may resume them as long as it is a RESUME with the same n); any other decode call on the context gives the parking lot up
   bool parked_valid = false;
@@ -757,6 +760,7 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   ctx->pend_n = n;
   ctx->pend_flags = (grow ? MILZMA_DECODE_GROW : 0u) | (resume ? MILZMA_DECODE_RESUME : 0u);
   ctx->stream_active = false;
+  ctx->promoted.clear();
   ctx->pending = true;
   if (n == 0) return MILZMA_OK;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -892,6 +896,7 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
     }
     if (round == 1) next = kLitLds4;
     if (again.empty()) continue;
+    ctx->promoted.insert(ctx->promoted.end(), again.begin(), again.end());
     if (!hip_ok(ctx,
                 hipMemcpyAsync(static_cast<uint32_t*>(ctx->order.p) + n, again.data(), again.size() * sizeof(uint32_t),
                                hipMemcpyHostToDevice, stream),
@@ -1386,21 +1391,27 @@ struct StreamedSlot {
   }
 };
 
-// streamed launches are for batches it pays for: at least this many units and output bytes (MILZMA_STREAM_MIN="units,bytes": tests
-// send small batches down the path)
-void stream_minimum(size_t* units, size_t* bytes) {
+// streamed launches are for batches it pays for: at least this many units and output bytes, of about one size (one pitch for all
+// slices: a ragged batch would reserve the largest unit's room for every unit).  MILZMA_STREAM_MIN="units,bytes[,1]": tests send small
+// batches down the path; the third field lifts the one-size condition too (fuzzers: batches of anything).
+void stream_minimum(size_t* units, size_t* bytes, bool* ragged_ok = nullptr) {
   static size_t mu = 256, mb = size_t(256) << 20;
+  static bool any = false;
   static const bool init = [] {
     if (const char* e = getenv("MILZMA_STREAM_MIN")) {
       char* end = nullptr;
       mu = size_t(strtoull(e, &end, 0));
-      if (end && *end == ',') mb = size_t(strtoull(end + 1, nullptr, 0));
+      if (end && *end == ',') {
+        mb = size_t(strtoull(end + 1, &end, 0));
+        if (end && *end == ',') any = strtoull(end + 1, nullptr, 0) != 0;
+      }
     }
     return true;
   }();
   (void)init;
   *units = mu;
   *bytes = mb;
+  if (ragged_ok) *ragged_ok = any;
 }
 
 bool pinned_results_wanted() {
@@ -1677,14 +1688,15 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
     size_t max_cap = 0;
     size_t min_units, min_bytes;
-    stream_minimum(&min_units, &min_bytes);
+    bool ragged_ok = false;
+    stream_minimum(&min_units, &min_bytes, &ragged_ok);
     bool all_fast = ctx->use_fast && !off && units.size() >= min_units && out_total >= min_bytes;
     for (const milzma_unit& u : units) {
       max_cap = std::max(max_cap, size_t(u.out_cap));
       all_fast = all_fast && classify(ctx, u) == kFast;
     }
     const size_t pitch = round_up(max_cap, 256);
-    if (all_fast && pitch * units.size() <= out_total + out_total / 4 && in_total + pitch * units.size() <= budget &&
+    if (all_fast && (ragged_ok || pitch * units.size() <= out_total + out_total / 4) && in_total + pitch * units.size() <= budget &&
         streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
       if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
@@ -1846,6 +1858,17 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         give_up(active);
         finish_alone();
         return MILZMA_INFRA_ERROR;
+      }
+      // (a unit that ran again in another class did so in a launch of its own, without host destinations: its bytes are on the device)
+      for (uint32_t k : ctx->promoted) {
+        const size_t got = size_t(std::min<uint64_t>(res[k].out_len, units[k].out_cap));
+        if (k < nu && bufs[k] && got &&
+            !hip_ok(ctx, hipMemcpy(bufs[k], static_cast<const uint8_t*>(ctx->out.p) + units[k].out_off, got, hipMemcpyDeviceToHost), "D2H output")) {
+          held.drop();
+          give_up(active);
+          finish_alone();
+          return MILZMA_INFRA_ERROR;
+        }
       }
       std::vector<uint32_t> parked;
       for (uint32_t k = 0; k < nu; k++) {
@@ -2165,7 +2188,22 @@ struct OutBuf {
       n += len;
       return true;
     }
-    if (!reserve(n + len)) return false;
+    // Bytes that are NOT at their place (a block decoded on demand, or one that is where the Index put it while the file stands
+    // elsewhere: the Index lied about an earlier block) are copied in.  In the first buffer of a streamed batch that copy would run over
+    // the places of the blocks behind it -- payloads the walk has yet to take, src itself perhaps: the file moves to a buffer of its own
+    // first and the first one is kept (`keep`) for as long as payloads may point into it.
+    if (hold_first && !keep && p) {
+      const size_t c = out_class(std::max<size_t>(std::max(cap, n + len), 4096));
+      uint8_t* q = out_alloc(c);
+      if (!q) return false;
+      if (n) memcpy(q, p, n);
+      keep = p;
+      p = q;
+      cap = c;
+      moved = true;
+    } else if (!reserve(n + len)) {
+      return false;
+    }
     if (len) memcpy(p + n, src, len);
     n += len;
     return true;
@@ -2520,8 +2558,9 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
     for (const milzma_unit& u : units) max_cap = std::max(max_cap, size_t(u.out_cap));
     const size_t pitch = round_up(max_cap, 256);
     size_t min_units, min_bytes;
-    stream_minimum(&min_units, &min_bytes);
-    if (ctx->use_fast && !off && nu >= min_units && out_total >= min_bytes && pitch * nu <= out_total + out_total / 4 &&
+    bool ragged_ok = false;
+    stream_minimum(&min_units, &min_bytes, &ragged_ok);
+    if (ctx->use_fast && !off && nu >= min_units && out_total >= min_bytes && (ragged_ok || pitch * nu <= out_total + out_total / 4) &&
         in_total + pitch * nu <= budget && streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
       if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
@@ -2654,15 +2693,22 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
             if (wr != MILZMA_OK) return false;
             streamed_done = true;
             streamed_direct = direct;
-            if (direct)   // (the waves wrote no more than the Index's size to a block's place: the rare longer block is fetched whole)
-              for (uint32_t k = 0; k < nu; k++)
-                if (res[k].status == MILZMA_ST_OK && res[k].out_len > refs[k].unpacked && res[k].out_len <= units[k].out_cap) {
-                  std::vector<uint8_t>& v = longer[k];
-                  v.resize(size_t(res[k].out_len));
-                  if (!hip_ok(ctx, hipMemcpy(v.data(), static_cast<const uint8_t*>(ctx->out.p) + units[k].out_off, v.size(), hipMemcpyDeviceToHost),
-                              "D2H block"))
-                    return false;
-                }
+            // fetched whole from the device: the rare block LONGER than the Index says (the waves wrote no more than the Index's size to
+            // its place), and a block that was decoded again in another launch class (that launch has no host destinations)
+            std::vector<uint8_t> fetch(nu, 0);
+            if (direct)
+              for (uint32_t k = 0; k < nu; k++) fetch[k] = res[k].out_len > refs[k].unpacked;
+            for (uint32_t k : ctx->promoted)
+              if (k < nu) fetch[k] = 1;
+            for (uint32_t k = 0; k < nu; k++)
+              if (fetch[k] && res[k].status == MILZMA_ST_OK && res[k].out_len <= units[k].out_cap) {
+                std::vector<uint8_t>& v = longer[k];
+                v.resize(size_t(res[k].out_len));
+                if (!v.empty() &&
+                    !hip_ok(ctx, hipMemcpy(v.data(), static_cast<const uint8_t*>(ctx->out.p) + units[k].out_off, v.size(), hipMemcpyDeviceToHost),
+                            "D2H block"))
+                  return false;
+              }
           } else if (milzma_decode_units_wait_impl(ctx, res.data()) != MILZMA_OK) {
             return false;
           }
@@ -2725,13 +2771,16 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
             // streamed: the block sits at its place in the file's buffer (and, unless the waves wrote it there themselves, in the
             // staging buffer too); classic: in the staging buffer
             p->data = streamed_done ? fb_base[i] + refs[k].blk_off : hout + units[k].out_off;
-            if (streamed_done && r.out_len == refs[k].unpacked) p->prefilled_at = refs[k].blk_off;
-            if (streamed_direct && r.out_len > refs[k].unpacked) {
+            if (streamed_done) {
               const auto lit = longer.find(k);
-              if (lit == longer.end()) return live(in, in_len, cap_hint, p);
-              p->data = lit->second.data();
-            } else if (streamed_done && !streamed_direct && r.out_len > refs[k].unpacked) {
-              p->data = hout + units[k].out_off;   // (whole in the staging buffer)
+              if (lit != longer.end()) {
+                p->data = lit->second.data();              // (fetched whole: see above)
+              } else if (r.out_len == refs[k].unpacked) {
+                p->prefilled_at = refs[k].blk_off;
+              } else if (r.out_len > refs[k].unpacked) {
+                if (streamed_direct) return live(in, in_len, cap_hint, p);
+                p->data = hout + units[k].out_off;         // (whole in the staging buffer)
+              }
             }
             crc_fold(parts + k * kCrcPartsBytes, r.out_len, &p->crc32, &p->crc64);
             p->has_crc = true;

@@ -1,0 +1,248 @@
+// tests/san/fake_hip.cpp -- TEST INFRASTRUCTURE.  A HIP runtime made of host memory and host threads, for the sanitizer builds of the
+// library's host side (tests/san/Makefile: pipeline_asan / pipeline_tsan).  With it -- and tests/san/fake_kernels.cpp, where the CPU oracle
+// stands in for the decode kernels -- the WHOLE of lzma_rs_amd/csrc/host.cpp runs without a GPU: staging, pools, streamed launches with their
+// consumer threads, park / regrow / resume rounds, lanes, asynchronous calls, the multi-device entry points.  What is checked there is the
+// host logic under AddressSanitizer / UndefinedBehaviorSanitizer / ThreadSanitizer; parity of the real kernels is the GPU suite's business.
+//
+// Model: "device memory" is malloc'd host memory (so ASan sees every out-of-bounds copy), page-locked memory likewise, a device pointer
+// to mapped host memory is the host pointer.  A stream is an in-order chain of tasks, each on a thread of its own (std::async), so that
+// work on different streams really overlaps and ThreadSanitizer sees the library's synchronisation, not the fake's.  Events are
+// tasks that take the time.  FAKE_HIP_DEVICES (default 1) devices, all alike, peer access everywhere.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <future>
+#include <mutex>
+#include <set>
+
+namespace {
+
+struct FakeStream {
+  std::mutex mu;
+  std::shared_future<void> tail;
+};
+struct FakeEvent {
+  std::mutex mu;
+  std::shared_future<void> done;
+  std::chrono::steady_clock::time_point at;
+};
+
+FakeStream g_null_stream;
+std::mutex g_streams_mu;
+std::set<FakeStream*> g_streams;
+thread_local int t_device = 0;
+
+FakeStream* S(hipStream_t s) { return s ? reinterpret_cast<FakeStream*>(s) : &g_null_stream; }
+
+void enqueue(FakeStream* s, std::function<void()> fn) {
+  std::lock_guard<std::mutex> lock(s->mu);
+  std::shared_future<void> prev = s->tail;
+  s->tail = std::async(std::launch::async, [prev, fn = std::move(fn)] {
+              if (prev.valid()) prev.wait();
+              fn();
+            }).share();
+}
+
+void drain(FakeStream* s) {
+  std::shared_future<void> t;
+  {
+    std::lock_guard<std::mutex> lock(s->mu);
+    t = s->tail;
+  }
+  if (t.valid()) t.wait();
+}
+
+void drain_all() {
+  std::set<FakeStream*> all;
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    all = g_streams;
+  }
+  for (FakeStream* s : all) drain(s);
+  drain(&g_null_stream);
+}
+
+int device_count() {
+  const char* e = getenv("FAKE_HIP_DEVICES");
+  const int n = e ? atoi(e) : 1;
+  return n < 1 ? 1 : n > 8 ? 8 : n;
+}
+
+}  // namespace
+
+// (tests/san/fake_kernels.cpp queues the stand-in kernels through this)
+void fake_hip_enqueue(hipStream_t stream, std::function<void()> fn) { enqueue(S(stream), std::move(fn)); }
+
+extern "C" {
+
+hipError_t hipGetDeviceCount(int* count) {
+  *count = device_count();
+  return hipSuccess;
+}
+hipError_t hipSetDevice(int device) {
+  if (device < 0 || device >= device_count()) return hipErrorInvalidDevice;
+  t_device = device;
+  return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int device) {
+  if (device < 0 || device >= device_count()) return hipErrorInvalidDevice;
+  memset(prop, 0, sizeof *prop);
+  strcpy(prop->name, "fake MI355X");
+  strcpy(prop->gcnArchName, "gfx950:sramecc+:xnack-");
+  prop->multiProcessorCount = 256;
+  prop->totalGlobalMem = size_t(16) << 30;
+  return hipSuccess;
+}
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "fake HIP error"; }
+
+hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+  drain_all();  // (hipFree synchronises the device)
+  free(p);
+  return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
+  *p = malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) {
+  drain_all();
+  free(p);
+  return hipSuccess;
+}
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned int) {
+  *dev = host;
+  return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+  *free_b = size_t(12) << 30;
+  *total_b = size_t(16) << 30;
+  return hipSuccess;
+}
+
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+  drain(&g_null_stream);
+  if (n) memmove(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t stream) {
+  enqueue(S(stream), [=] {
+    if (n) memmove(dst, src, n);
+  });
+  return hipSuccess;
+}
+hipError_t hipMemcpyPeer(void* dst, int, const void* src, int, size_t n) {
+  drain(&g_null_stream);
+  if (n) memmove(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipMemsetD16Async(hipDeviceptr_t dst, unsigned short v, size_t count, hipStream_t stream) {
+  enqueue(S(stream), [=] {
+    unsigned short* p = static_cast<unsigned short*>(dst);
+    for (size_t i = 0; i < count; i++) p[i] = v;
+  });
+  return hipSuccess;
+}
+
+hipError_t hipStreamCreateWithFlags(hipStream_t* out, unsigned int) {
+  FakeStream* s = new FakeStream();
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    g_streams.insert(s);
+  }
+  *out = reinterpret_cast<hipStream_t>(s);
+  return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* out) { return hipStreamCreateWithFlags(out, 0); }
+hipError_t hipStreamDestroy(hipStream_t stream) {
+  if (!stream) return hipSuccess;
+  FakeStream* s = S(stream);
+  drain(s);
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    g_streams.erase(s);
+  }
+  delete s;
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t stream) {
+  drain(S(stream));
+  return hipSuccess;
+}
+hipError_t hipDeviceSynchronize(void) {
+  drain_all();
+  return hipSuccess;
+}
+
+hipError_t hipEventCreateWithFlags(hipEvent_t* out, unsigned) {
+  *out = reinterpret_cast<hipEvent_t>(new FakeEvent());
+  return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t* out) { return hipEventCreateWithFlags(out, 0); }
+hipError_t hipEventDestroy(hipEvent_t e) {
+  FakeEvent* ev = reinterpret_cast<FakeEvent*>(e);
+  std::shared_future<void> d;
+  {
+    std::lock_guard<std::mutex> lock(ev->mu);
+    d = ev->done;
+  }
+  if (d.valid()) d.wait();
+  delete ev;
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t stream) {
+  FakeEvent* ev = reinterpret_cast<FakeEvent*>(e);
+  FakeStream* s = S(stream);
+  std::lock_guard<std::mutex> lock(s->mu);
+  std::shared_future<void> prev = s->tail;
+  s->tail = std::async(std::launch::async, [prev, ev] {
+              if (prev.valid()) prev.wait();
+              std::lock_guard<std::mutex> l2(ev->mu);
+              ev->at = std::chrono::steady_clock::now();
+            }).share();
+  std::lock_guard<std::mutex> l3(ev->mu);
+  ev->done = s->tail;
+  return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+  FakeEvent* ev = reinterpret_cast<FakeEvent*>(e);
+  std::shared_future<void> d;
+  {
+    std::lock_guard<std::mutex> lock(ev->mu);
+    d = ev->done;
+  }
+  if (d.valid()) d.wait();
+  return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  hipEventSynchronize(a);
+  hipEventSynchronize(b);
+  FakeEvent *ea = reinterpret_cast<FakeEvent*>(a), *eb = reinterpret_cast<FakeEvent*>(b);
+  std::chrono::steady_clock::time_point ta, tb;
+  {
+    std::lock_guard<std::mutex> lock(ea->mu);
+    ta = ea->at;
+  }
+  {
+    std::lock_guard<std::mutex> lock(eb->mu);
+    tb = eb->at;
+  }
+  *ms = std::chrono::duration<float, std::milli>(tb - ta).count();
+  return hipSuccess;
+}
+
+hipError_t hipDeviceCanAccessPeer(int* can, int, int) {
+  *can = 1;
+  return hipSuccess;
+}
+hipError_t hipDeviceEnablePeerAccess(int, unsigned int) { return hipSuccess; }
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// tests/san/fake_kernels.cpp -- TEST INFRASTRUCTURE.  Stand-ins for the kernel launchers of lzma_rs_amd/csrc/kernels.h in the sanitizer
+// builds of the host side (tests/san/Makefile: pipeline_asan / pipeline_tsan; see fake_hip.cpp).  The CPU oracle decodes a unit where the
+// GPU kernels would; what these stand-ins keep of the real kernels is their CONTRACT with the host code:
+//   * one milzma_result per unit (status, out_len, out_flushed, in_consumed), written when the launch's task runs on its stream;
+//   * growable output: a unit that does not fit its slice is parked (OUT_FULL, err_a = MILZMA_PARKED, out_len = what is in the slice) if the
+//     launch is a growing one, and continues -- here: is decoded again into the larger slice -- when an order entry with bit 31 names it;
+//   * streamed launches: every unit's output also goes to its host destination (host_ptrs {address, limit} or host_out + out_off), then
+//     the span counters move; a launch with an in_ready word waits for it before it reads beyond the units' leads (here: before it reads).
+// Only streams the oracle decodes without an error -- and truncated ones (INPUT_EOF) -- get a faithful status; any other failure is reported as
+// MILZMA_ST_L2_INVALID_STATUS / MILZMA_ST_LZ_DIST_DICT with the oracle's bytes: the harness (pipeline_fuzz.cpp) compares what the reference
+// defines for such inputs only where the status is faithful.
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "kernels.h"
+#include "lzma_oracle.h"
+
+void fake_hip_enqueue(hipStream_t stream, std::function<void()> fn);
+extern "C" uint32_t milzma_crc32(const uint8_t* p, size_t n);
+extern "C" uint64_t milzma_crc64(const uint8_t* p, size_t n);
+
+namespace {
+
+struct Streamed {
+  uint32_t span = 0, n_spans = 0;
+  uint32_t* progress = nullptr;
+  uint8_t* host_out = nullptr;
+  uint32_t* in_ready = nullptr;
+  const uint64_t* host_ptrs = nullptr;
+};
+
+// lc + lp of the first LZMA chunk of an LZMA2 stream that brings properties (control >= 0xC0: lzma2.rs:153-175), 0 if there is none in front
+uint32_t first_lclp(const uint8_t* in, size_t n) {
+  size_t pos = 0;
+  while (pos < n) {
+    const uint8_t c = in[pos];
+    if (c == 0) return 0;
+    if (c < 0x80) {  // stored chunk: 2 size bytes + data
+      if (pos + 3 > n) return 0;
+      pos += 3 + ((size_t(in[pos + 1]) << 8) | in[pos + 2]) + 1;
+      continue;
+    }
+    if (c >= 0xC0 && pos + 5 < n) {
+      const uint32_t props = in[pos + 5];
+      if (props >= 225) return 0;
+      return (props % 9) + ((props / 9) % 5);
+    }
+    return 0;
+  }
+  return 0;
+}
+
+void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_t* d_out, milzma_result* res, bool grow, const Streamed* st,
+                bool has_slab) {
+  milzma_result r;
+  memset(&r, 0, sizeof r);
+  orc_result o;
+  memset(&o, 0, sizeof o);
+  const uint8_t* in = d_in + u.in_off;
+  // like the fast kernel without a literal-row slab: an LZMA2 unit whose chunk asks for lc + lp = 4 is sent back for another launch class
+  if (u.kind == MILZMA_KIND_LZMA2 && !has_slab && first_lclp(in, size_t(u.in_len)) == 4) {
+    r.status = MILZMA_ST_NEED_GENERIC;
+    if (st && st->progress)
+      for (uint32_t s = 0; s < st->n_spans; s++) __atomic_fetch_add(&st->progress[s], 1u, __ATOMIC_RELEASE);
+    res[uidx] = r;
+    return;
+  }
+  int kind;
+  if (u.kind == MILZMA_KIND_LZMA2)
+    kind = orc_lzma2_decompress(in, size_t(u.in_len), &o);
+  else
+    kind = orc_lzma_raw_decompress(in, size_t(u.in_len), u.lc, u.lp, u.pb, u.dict_size, u.unpacked_size != MILZMA_SIZE_UNKNOWN, u.unpacked_size,
+                                   u.memlimit != MILZMA_NO_LIMIT, u.memlimit, &o);
+  uint8_t* out = d_out + u.out_off;
+  size_t visible = o.out_len;
+  if (kind == ORC_OK && o.out_len > u.out_cap) {  // does not fit: parked in front of the symbol that would not (here: a little before the end)
+    r.status = MILZMA_ST_OUT_FULL;
+    r.err_a = grow ? MILZMA_PARKED : 0;
+    visible = size_t(u.out_cap > 300 ? u.out_cap - 300 : 0);
+    r.out_len = r.out_flushed = visible;
+    r.in_consumed = 0;
+  } else {
+    visible = size_t(o.out_len < u.out_cap ? o.out_len : u.out_cap);
+    r.out_len = r.out_flushed = visible;
+    r.in_consumed = o.in_consumed;
+    if (kind == ORC_OK)
+      r.status = MILZMA_ST_OK;
+    else if (strstr(o.msg, "failed to fill whole buffer") && kind == ORC_IO_ERROR)
+      r.status = MILZMA_ST_INPUT_EOF;
+    else if (strstr(o.msg, "too short: failed to fill whole buffer"))   // "LZMA stream too short" / "LZMA input too short": the range coder's first bytes
+      r.status = MILZMA_ST_RC_INIT;
+    else
+      r.status = u.kind == MILZMA_KIND_LZMA2 ? MILZMA_ST_L2_INVALID_STATUS : MILZMA_ST_LZ_DIST_DICT;
+  }
+  if (visible) memcpy(out, o.out, visible);
+  if (st && st->progress) {  // the streamed way out: the unit's own destination, then the counters
+    uint8_t* host = st->host_out ? st->host_out + u.out_off : nullptr;
+    size_t end = visible;
+    if (st->host_ptrs) {
+      host = reinterpret_cast<uint8_t*>(uintptr_t(st->host_ptrs[2 * size_t(uidx)]));
+      const uint64_t lim = st->host_ptrs[2 * size_t(uidx) + 1];
+      if (end > lim) end = size_t(lim);
+    }
+    if (host && end) memcpy(host, out, end);
+    for (uint32_t s = 0; s < st->n_spans; s++) __atomic_fetch_add(&st->progress[s], 1u, __ATOMIC_RELEASE);
+  }
+  orc_free(o.out);
+  res[uidx] = r;
+}
+
+void run_units(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
+               bool grow, Streamed st, bool has_slab) {
+  if (st.in_ready)
+    while (__atomic_load_n(st.in_ready, __ATOMIC_ACQUIRE) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+  // a few host threads stand for the chip: units really finish in any order and at the same time
+  const unsigned t = n < 4 ? 1u : 4u;
+  std::vector<std::thread> th;
+  const auto body = [&](unsigned k) {
+    for (uint32_t i = k; i < n; i += t) {
+      const uint32_t uidx = d_order[i] & 0x7FFFFFFFu;
+      decode_one(d_units[uidx], uidx, d_in, d_out, d_results, grow, st.progress ? &st : nullptr, has_slab);
+    }
+  };
+  for (unsigned k = 1; k < t; k++) th.emplace_back(body, k);
+  body(0);
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+namespace milzma {
+
+hipError_t launch_generic(LitClass, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
+                          milzma_result* d_results, uint16_t*, uint32_t, hipStream_t stream) {
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), true); });
+  return hipSuccess;
+}
+hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
+                       hipStream_t stream, uint32_t, uint32_t*, const uint8_t* d_slab, uint32_t) {
+  const bool has_slab = d_slab != nullptr;
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), has_slab); });
+  return hipSuccess;
+}
+uint32_t fast_resident_blocks(uint32_t) { return 16; }   // (a small chip: launches of more units than that take the time-sliced form)
+size_t slice_ctx_bytes() { return 64; }
+size_t slice_queue_bytes(uint32_t cap) { return size_t(cap) * 8 + 64; }
+hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
+                              milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool grow,
+                              uint32_t span_bytes, uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready,
+                              const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t) {
+  Streamed st;
+  st.span = span_bytes;
+  st.n_spans = n_spans;
+  st.progress = progress;
+  st.host_out = host_out;
+  st.in_ready = in_ready;
+  st.host_ptrs = host_ptrs;
+  const bool has_slab = d_slab != nullptr;
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, grow, st, has_slab); });
+  return hipSuccess;
+}
+uint32_t stream_lead_bytes(uint32_t in_len) {
+  const uint32_t q4 = in_len >> 2;
+  return q4 > 4096u ? q4 : 4096u;   // (the real kernels: a quarter, at least 128 KiB -- small here, so that small files have a second part)
+}
+hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream) {
+  fake_hip_enqueue(stream, [=] {
+    for (uint32_t i = 0; i < n; i++)
+      if (d_offs[2 * size_t(n) + i]) memmove(d_dst + d_offs[size_t(n) + i], d_src + d_offs[i], size_t(d_offs[2 * size_t(n) + i]));
+  });
+  return hipSuccess;
+}
+// crc_units.hip.h: 64 chunks per unit, the partial CRCs of each, folded by host.cpp's crc_fold
+hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results, void* d_parts,
+                            hipStream_t stream) {
+  fake_hip_enqueue(stream, [=] {
+    uint8_t* parts = static_cast<uint8_t*>(d_parts);
+    for (uint32_t u = 0; u < n; u++) {
+      uint8_t* p = parts + size_t(u) * kCrcPartsBytes;
+      uint32_t* c32 = reinterpret_cast<uint32_t*>(p);
+      uint64_t* c64 = reinterpret_cast<uint64_t*>(p + 64 * 4);
+      uint32_t valid = d_results[u].status == MILZMA_ST_OK;
+      const uint64_t len = d_results[u].out_len;
+      uint64_t chunk = ((len + 63) / 64 + 15) & ~uint64_t(15);
+      if (chunk == 0) chunk = 16;
+      const uint8_t* base = d_out + d_units[u].out_off;
+      for (uint32_t l = 0; l < 64; l++) {
+        const uint64_t begin = uint64_t(l) * chunk, end = begin + chunk < len ? begin + chunk : len;
+        const bool some = valid && begin < end;
+        c32[l] = some ? milzma_crc32(base + begin, size_t(end - begin)) : 0;
+        c64[l] = some ? milzma_crc64(base + begin, size_t(end - begin)) : 0;
+      }
+      const uint32_t ch = uint32_t(chunk);
+      memcpy(p + 64 * 4 + 64 * 8, &ch, 4);
+      memcpy(p + 64 * 4 + 64 * 8 + 4, &valid, 4);
+    }
+  });
+  return hipSuccess;
+}
+
+}  // namespace milzma

@@ -1,0 +1,337 @@
+// tests/san/pipeline_fuzz.cpp -- TEST INFRASTRUCTURE (built by tests/san/Makefile with fake_hip.cpp + fake_kernels.cpp, run by
+// tests/test_host_pipeline_sanitized.py).  Drives the library's GPU entry points -- whole-file batches (.lzma, LZMA2, .xz), single files, the
+// asynchronous halves on two contexts, large calls cut into groups, the multi-device calls incl. the one-ingest-point entry -- through the
+// fake HIP runtime, under AddressSanitizer + UndefinedBehaviorSanitizer or ThreadSanitizer, and compares every result with the oracle where
+// the stand-in kernels report a faithful status (streams that decode, and truncated ones).
+//
+//   pipeline_fuzz <dir with *.lzma / *.lzma2 / *.xz> <rounds> <rng seed>
+//
+// Which paths a run takes is a matter of the environment (MILZMA_STREAM_MIN, MILZMA_PINNED_OUT, MILZMA_TWO_PART, MILZMA_STREAM,
+// FAKE_HIP_DEVICES, ...): the test runs the matrix.
+#include <dirent.h>
+
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lzma_oracle.h"
+#include "milzma.h"
+
+namespace {
+
+struct Rng {
+  uint64_t s;
+  uint32_t next() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return uint32_t(s >> 16);
+  }
+  uint32_t below(uint32_t n) { return n ? next() % n : 0; }
+};
+
+enum Kind { LZMA, LZMA2, XZ };
+struct Case {
+  std::string name;
+  Kind kind;
+  std::vector<uint8_t> data;
+};
+
+uint64_t g_cases = 0, g_compared = 0, g_skipped = 0;
+
+const uint8_t* ptr_of(const std::vector<uint8_t>& d) { return d.empty() ? reinterpret_cast<const uint8_t*>("") : d.data(); }
+
+// the oracle's verdict on one file; faithful: the stand-in kernels report this kind of outcome as the real ones would
+struct Want {
+  orc_result r;
+  bool faithful;
+};
+Want oracle_of(const Case& c) {
+  Want w;
+  memset(&w.r, 0, sizeof w.r);
+  const uint8_t* p = ptr_of(c.data);
+  if (c.kind == LZMA)
+    orc_lzma_decompress(p, c.data.size(), nullptr, &w.r);
+  else if (c.kind == LZMA2)
+    orc_lzma2_decompress(p, c.data.size(), &w.r);
+  else
+    orc_xz_decompress(p, c.data.size(), &w.r);
+  const bool eof = strstr(w.r.msg, "failed to fill whole buffer") != nullptr;
+  const bool payload_msg = strstr(w.r.msg, "LZMA2") || strstr(w.r.msg, "distance") || strstr(w.r.msg, "marker") || strstr(w.r.msg, "Expected unpacked");
+  w.faithful = w.r.kind == ORC_OK || (eof && !strstr(w.r.msg, "LZMA2")) || (c.kind == XZ && !payload_msg && !eof);
+  return w;
+}
+
+bool check(const Case& c, const milzma_output& o, const char* via) {
+  g_cases++;
+  Want w = oracle_of(c);
+  bool ok = true;
+  if (w.faithful) {
+    g_compared++;
+    ok = o.kind == w.r.kind && strcmp(o.msg, w.r.msg) == 0 && o.len == w.r.out_len && (o.len == 0 || memcmp(o.data, w.r.out, o.len) == 0) &&
+         o.in_consumed == w.r.in_consumed;
+    if (!ok)
+      printf("MISMATCH %s via %s (%zu bytes): got kind %d '%s' len %zu consumed %zu | oracle kind %d '%s' len %zu consumed %zu\n", c.name.c_str(), via,
+             c.data.size(), o.kind, o.msg, o.len, o.in_consumed, w.r.kind, w.r.msg, w.r.out_len, w.r.in_consumed);
+  } else {
+    g_skipped++;
+    ok = o.kind != MILZMA_OK && o.kind != MILZMA_INFRA_ERROR;   // (some reference error; which one is the real kernels' business)
+    if (!ok) printf("MISMATCH %s via %s: oracle fails with '%s', the library says kind %d '%s'\n", c.name.c_str(), via, w.r.msg, o.kind, o.msg);
+  }
+  orc_free(w.r.out);
+  return ok;
+}
+
+typedef int (*BatchFn)(milzma_ctx*, uint32_t, const uint8_t* const*, const size_t*, milzma_output*);
+int lzma_batch(milzma_ctx* c, uint32_t n, const uint8_t* const* i, const size_t* l, milzma_output* o) { return milzma_lzma_decompress_batch(c, n, i, l, nullptr, o); }
+int lzma_batch_async(milzma_ctx* c, uint32_t n, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+  return milzma_lzma_decompress_batch_async(c, n, i, l, nullptr, o);
+}
+typedef int (*MultiFn)(milzma_multi*, uint32_t, const uint8_t* const*, const size_t*, milzma_output*);
+int multi_lzma(milzma_multi* m, uint32_t n, const uint8_t* const* i, const size_t* l, milzma_output* o) {
+  return milzma_multi_lzma_decompress_batch(m, n, i, l, nullptr, o);
+}
+
+struct Batch {
+  std::vector<const Case*> cases;
+  std::vector<const uint8_t*> ins;
+  std::vector<size_t> lens;
+  std::vector<milzma_output> outs;
+  void add(const Case* c) {
+    cases.push_back(c);
+    ins.push_back(ptr_of(c->data));
+    lens.push_back(c->data.size());
+  }
+  void prepare() {
+    outs.assign(cases.size(), milzma_output());
+    for (auto& o : outs) memset(&o, 0, sizeof o);
+  }
+  bool verify(const char* via) {
+    bool ok = true;
+    for (size_t i = 0; i < cases.size(); i++) {
+      ok = check(*cases[i], outs[i], via) && ok;
+      milzma_free(outs[i].data);
+    }
+    return ok;
+  }
+};
+
+bool run_batch(milzma_ctx* ctx, Kind kind, Batch& b, const char* via) {
+  b.prepare();
+  const uint32_t n = uint32_t(b.cases.size());
+  int rc;
+  if (kind == LZMA)
+    rc = lzma_batch(ctx, n, b.ins.data(), b.lens.data(), b.outs.data());
+  else if (kind == LZMA2)
+    rc = milzma_lzma2_decompress_batch(ctx, n, b.ins.data(), b.lens.data(), b.outs.data());
+  else
+    rc = milzma_xz_decompress_batch(ctx, n, b.ins.data(), b.lens.data(), b.outs.data());
+  if (rc == MILZMA_INFRA_ERROR) {
+    printf("INFRA %s: %s\n", via, milzma_last_error(ctx));
+    return false;
+  }
+  return b.verify(via);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    fprintf(stderr, "usage: pipeline_fuzz <dir> <rounds> <rng seed>\n");
+    return 2;
+  }
+  const std::string dir = argv[1];
+  const int rounds = atoi(argv[2]);
+  Rng rng{0x9E3779B97F4A7C15ull ^ strtoull(argv[3], nullptr, 0)};
+  std::vector<Case> pool[3];
+  if (DIR* dp = opendir(dir.c_str())) {
+    while (dirent* e = readdir(dp)) {
+      const std::string name = e->d_name;
+      Kind k;
+      if (name.size() > 5 && name.compare(name.size() - 5, 5, ".lzma") == 0)
+        k = LZMA;
+      else if (name.size() > 6 && name.compare(name.size() - 6, 6, ".lzma2") == 0)
+        k = LZMA2;
+      else if (name.size() > 3 && name.compare(name.size() - 3, 3, ".xz") == 0)
+        k = XZ;
+      else
+        continue;
+      if (FILE* f = fopen((dir + "/" + name).c_str(), "rb")) {
+        Case c{name, k, {}};
+        uint8_t buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) c.data.insert(c.data.end(), buf, buf + n);
+        fclose(f);
+        pool[k].push_back(std::move(c));
+      }
+    }
+    closedir(dp);
+  }
+  if (pool[LZMA].empty() || pool[LZMA2].empty() || pool[XZ].empty()) {
+    fprintf(stderr, "need .lzma, .lzma2 and .xz files in %s\n", dir.c_str());
+    return 2;
+  }
+  // truncated variants (the one failure the stand-in kernels report faithfully) + a few garbage tails
+  for (int k = 0; k < 3; k++) {
+    const size_t n0 = pool[k].size();
+    for (size_t i = 0; i < n0; i++) {
+      for (int v = 0; v < 2; v++) {
+        Case c = pool[k][i];
+        if (c.data.size() < 4) continue;
+        c.data.resize(v == 0 ? c.data.size() / 2 : c.data.size() - 1 - rng.below(uint32_t(std::min<size_t>(c.data.size() - 1, 40))));
+        c.name += v == 0 ? " (half)" : " (tail cut)";
+        pool[k].push_back(std::move(c));
+      }
+    }
+  }
+  milzma_ctx *ctx = nullptr, *ctx2 = nullptr;
+  if (milzma_create(0, &ctx) != MILZMA_OK || milzma_create(0, &ctx2) != MILZMA_OK) {
+    fprintf(stderr, "milzma_create: %s\n", milzma_last_error(nullptr));
+    return 1;
+  }
+  bool ok = true;
+  const char* kname[3] = {"lzma batch", "lzma2 batch", "xz batch"};
+  for (int round = 0; round < rounds && ok; round++) {
+    for (int k = 0; k < 3 && ok; k++) {
+      // 1. one batch of a random selection (with repeats: two units of a batch may share their input bytes)
+      Batch b;
+      const uint32_t n = 1 + rng.below(uint32_t(pool[k].size()) * 2);
+      for (uint32_t i = 0; i < n; i++) b.add(&pool[k][rng.below(uint32_t(pool[k].size()))]);
+      ok = run_batch(ctx, Kind(k), b, kname[k]) && ok;
+      // 2. single-file calls
+      for (int j = 0; j < 3 && ok; j++) {
+        const Case& c = pool[k][rng.below(uint32_t(pool[k].size()))];
+        milzma_output o;
+        memset(&o, 0, sizeof o);
+        if (k == LZMA)
+          milzma_lzma_decompress(ctx, ptr_of(c.data), c.data.size(), nullptr, &o);
+        else if (k == LZMA2)
+          milzma_lzma2_decompress(ctx, ptr_of(c.data), c.data.size(), &o);
+        else
+          milzma_xz_decompress(ctx, ptr_of(c.data), c.data.size(), &o);
+        ok = check(c, o, "single") && ok;
+        milzma_free(o.data);
+      }
+    }
+    // 3. two calls in flight on two contexts (the asynchronous halves)
+    {
+      Batch a, b;
+      for (uint32_t i = 0; i < 12; i++) {
+        a.add(&pool[LZMA][rng.below(uint32_t(pool[LZMA].size()))]);
+        b.add(&pool[XZ][rng.below(uint32_t(pool[XZ].size()))]);
+      }
+      a.prepare();
+      b.prepare();
+      const int ra = lzma_batch_async(ctx, uint32_t(a.cases.size()), a.ins.data(), a.lens.data(), a.outs.data());
+      const int rb = milzma_xz_decompress_batch_async(ctx2, uint32_t(b.cases.size()), b.ins.data(), b.lens.data(), b.outs.data());
+      if (ra != MILZMA_OK || rb != MILZMA_OK) {
+        printf("INFRA async begin: %s / %s\n", milzma_last_error(ctx), milzma_last_error(ctx2));
+        ok = false;
+      }
+      const int wa = milzma_batch_wait(ctx), wb = milzma_batch_wait(ctx2);
+      if (wa == MILZMA_INFRA_ERROR || wb == MILZMA_INFRA_ERROR) {
+        printf("INFRA async wait: %s / %s\n", milzma_last_error(ctx), milzma_last_error(ctx2));
+        ok = false;
+      }
+      ok = a.verify("async lzma") && ok;
+      ok = b.verify("async xz") && ok;
+    }
+  }
+  // 4. a call large enough to be cut into groups over lanes (>= 8192 units): tiny files, many times
+  if (ok && getenv("PIPELINE_BIG")) {
+    Batch b;
+    const Case* tiny = &pool[LZMA][0];
+    for (const Case& c : pool[LZMA])
+      if (c.data.size() < tiny->data.size() && c.data.size() > 20) tiny = &c;
+    for (uint32_t i = 0; i < 8192 + 300; i++) b.add(i % 7 == 0 ? &pool[LZMA][rng.below(uint32_t(pool[LZMA].size()))] : tiny);
+    ok = run_batch(ctx, LZMA, b, "lzma batch in groups") && ok;
+  }
+  // 5. several devices behind one handle (FAKE_HIP_DEVICES > 1, or MILZMA_MULTI_REPLICAS)
+  if (ok) {
+    milzma_multi* m = nullptr;
+    if (milzma_multi_create(0, &m) != MILZMA_OK) {
+      printf("INFRA multi create: %s\n", milzma_multi_last_error(nullptr));
+      ok = false;
+    } else {
+      for (int k = 0; k < 3 && ok; k++) {
+        Batch b;
+        for (uint32_t i = 0; i < 20; i++) b.add(&pool[k][rng.below(uint32_t(pool[k].size()))]);
+        b.prepare();
+        const uint32_t n = uint32_t(b.cases.size());
+        const int rc = k == LZMA    ? multi_lzma(m, n, b.ins.data(), b.lens.data(), b.outs.data())
+                       : k == LZMA2 ? milzma_multi_lzma2_decompress_batch(m, n, b.ins.data(), b.lens.data(), b.outs.data())
+                                    : milzma_multi_xz_decompress_batch(m, n, b.ins.data(), b.lens.data(), b.outs.data());
+        if (rc == MILZMA_INFRA_ERROR) {
+          printf("INFRA multi batch: %s\n", milzma_multi_last_error(m));
+          ok = false;
+        }
+        ok = b.verify("multi batch") && ok;
+      }
+      // the unit-level calls: host buffers, and the one-ingest-point entry ("device" memory is host memory under the fake runtime)
+      if (ok) {
+        std::vector<const Case*> cs;
+        for (const Case& c : pool[LZMA2]) {
+          Want w = oracle_of(c);
+          if (w.r.kind == ORC_OK) cs.push_back(&c);
+          orc_free(w.r.out);
+        }
+        std::vector<milzma_unit> units(cs.size());
+        std::vector<uint8_t> in, out;
+        size_t io = 0, oo = 0;
+        std::vector<orc_result> want(cs.size());
+        for (size_t i = 0; i < cs.size(); i++) {
+          memset(&want[i], 0, sizeof want[i]);
+          orc_lzma2_decompress(ptr_of(cs[i]->data), cs[i]->data.size(), &want[i]);
+          memset(&units[i], 0, sizeof units[i]);
+          units[i].kind = MILZMA_KIND_LZMA2;
+          units[i].in_off = io;
+          units[i].in_len = cs[i]->data.size();
+          units[i].out_off = oo;
+          units[i].out_cap = want[i].out_len + 16 + (i % 3) * 5;   // (unaligned slices on purpose)
+          io += (cs[i]->data.size() + 255) & ~size_t(255);
+          oo += size_t(units[i].out_cap);
+        }
+        in.assign(io + 512, 0);
+        for (size_t i = 0; i < cs.size(); i++) memcpy(in.data() + units[i].in_off, ptr_of(cs[i]->data), cs[i]->data.size());
+        for (int form = 0; form < 2 && ok; form++) {
+          out.assign(oo + 512, 0xAA);
+          std::vector<milzma_result> res(cs.size());
+          const int rc = form == 0 ? milzma_multi_decode_units_host(m, units.data(), uint32_t(units.size()), in.data(), io, out.data(), oo, res.data())
+                                   : milzma_multi_decode_units_rooted(m, 0, units.data(), uint32_t(units.size()), in.data(), out.data(), res.data());
+          if (rc != MILZMA_OK) {
+            printf("INFRA multi units (form %d): %s\n", form, milzma_multi_last_error(m));
+            ok = false;
+            break;
+          }
+          for (size_t i = 0; i < cs.size(); i++) {
+            g_cases++;
+            g_compared++;
+            if (res[i].status != MILZMA_ST_OK || res[i].out_len != want[i].out_len ||
+                (want[i].out_len && memcmp(out.data() + units[i].out_off, want[i].out, want[i].out_len) != 0) ||
+                (form == 1 && out[units[i].out_off + want[i].out_len] != 0xAA)) {   // (the rooted form writes a unit's bytes and nothing else)
+              printf("MISMATCH unit %zu (%s) of the multi-device unit call, form %d: status %u len %" PRIu64 "\n", i, cs[i]->name.c_str(), form,
+                     res[i].status, res[i].out_len);
+              ok = false;
+            }
+          }
+        }
+        for (auto& w : want) orc_free(w.out);
+      }
+      milzma_multi_destroy(m);
+    }
+  }
+  milzma_destroy(ctx2);
+  milzma_destroy(ctx);
+  const size_t pooled = milzma_pool_trim(0);
+  if (pooled != 0) {
+    printf("MISMATCH: %zu bytes still pooled after milzma_pool_trim(0)\n", pooled);
+    ok = false;
+  }
+  if (!ok) return 1;
+  printf("ok cases=%" PRIu64 " compared=%" PRIu64 " unfaithful_status_skipped=%" PRIu64 "\n", g_cases, g_compared, g_skipped);
+  return 0;
+}

@@ -1,0 +1,99 @@
+"""The WHOLE host side of the library (lzma_rs_amd/csrc/host.cpp: staging, pools, streamed launches and their consumer threads, park /
+regrow / resume rounds, lanes, the asynchronous halves, the multi-device entry points incl. the one-ingest-point one) under
+AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer -- without a GPU.
+
+tests/san/fake_hip.cpp is a HIP runtime made of host memory and host threads (a stream = an in-order chain of tasks on threads of their own, so
+work on different streams really overlaps), tests/san/fake_kernels.cpp lets the CPU oracle decode a unit where the kernels would and keeps the
+kernels' contract with the host code (results, parking, span counters, the input-ready word).  tests/san/pipeline_fuzz.cpp drives the public
+entry points over valid and truncated .lzma / LZMA2 / .xz inputs and compares every result with the oracle.  What this checks is the HOST
+logic -- memory safety, data races, and that its many paths all hand the caller the right bytes; parity of the real kernels is `-m gpu`'s business.
+The product library never contains any of this: the fake runtime, the stand-in kernels and the oracle are linked into the test binary only."""
+import lzma
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SAN = os.path.join(ROOT, "tests", "san")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+from lzma_rs_amd import workloads as W  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pipeline_inputs")
+    rnd = random.Random(5)
+    for kind in ("text", "random", "repeat", "zeros"):
+        for size in (0, 1, 700, 20000, 150000):
+            plain = W.make_plain(kind, size, seed=rnd.randrange(1 << 30))
+            for known in (True, False):
+                lc, lp, pb = rnd.choice(((3, 0, 2), (0, 0, 0), (4, 0, 4), (1, 2, 3), (2, 1, 1)))
+                (d / ("%s_%d_%d.lzma" % (kind, size, known))).write_bytes(
+                    W.compress_alone(plain, dict_size=rnd.choice((1 << 12, 1 << 16, 1 << 20)), lc=lc, lp=lp, pb=pb, known_size=known))
+            # (lc + lp = 4: an LZMA2 unit of the fast class is sent back and decoded again in another launch class -- a streamed launch's
+            #  host destinations then hold nothing of it; round 4's GPU fuzz found the hand-over taking them at their word)
+            for lc, lp in ((3, 0), (2, 2)):
+                flt = [{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16, "lc": lc, "lp": lp, "pb": 2}]
+                (d / ("%s_%d_%d%d.lzma2" % (kind, size, lc, lp))).write_bytes(lzma.compress(plain, format=lzma.FORMAT_RAW, filters=flt))
+            for bs, chk in ((1 << 16, "crc64"), (1 << 14, "crc32"), (1 << 20, "none")):
+                (d / ("%s_%d_%d_%s.xz" % (kind, size, bs, chk))).write_bytes(W.compress_xz_blocks(plain, block_size=bs, check=chk))
+            flt = [{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16, "lc": 1, "lp": 3, "pb": 0}]
+            (d / ("%s_%d_lclp4.xz" % (kind, size))).write_bytes(lzma.compress(plain, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=flt))
+    # .xz files whose Index lies about a block's size (by a little: the block still fits its slice but not its place; by a lot: its unit
+    # runs out of room and the block is decoded on demand -- then COPIED into a buffer whose later places already hold the next blocks:
+    # round 4's GPU fuzz found that copy running over them; ASan's memcpy-param-overlap finds it here)
+    import test_xz_literals as X
+    blocks = [W.make_plain("text", 60000, seed=900 + i) for i in range(3)]
+    for lie in (8, 4000, 60000, -5000):
+        bl = [X.block(b, check=4) for b in blocks]
+        idx = X.index([(bl[0][1], bl[0][2]), (bl[1][1], bl[1][2] - lie), (bl[2][1], bl[2][2])])
+        (d / ("liar_%d.xz" % lie)).write_bytes(X.xz_file(check=4, blocks=bl, idx=idx))
+    return str(d)
+
+
+@pytest.fixture(scope="module")
+def binaries(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang with sanitizer runtimes in this image")
+    out = str(tmp_path_factory.mktemp("pipeline_build"))
+    r = subprocess.run(["make", "-C", SAN, "-s", "OUT=" + out, out + "/pipeline_asan", out + "/pipeline_tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return {"asan": out + "/pipeline_asan", "tsan": out + "/pipeline_tsan"}
+
+
+# what each run sends the calls through (the library reads these once per process)
+STREAMED = {"MILZMA_STREAM_MIN": "1,1,1"}          # every batch of the fast class through the streamed launch, whatever its shape
+MATRIX = {
+    "default": {},
+    "streamed": STREAMED,
+    "streamed-pageable": dict(STREAMED, MILZMA_PINNED_OUT="0"),
+    "streamed-two-part-xz": dict(STREAMED, MILZMA_TWO_PART="1"),
+    "streamed-three-devices": dict(STREAMED, FAKE_HIP_DEVICES="3"),
+    "replicas-copy-home": {"MILZMA_MULTI_REPLICAS": "3", "MILZMA_ROOTED_STREAM": "0"},
+    "groups-over-lanes": {"PIPELINE_BIG": "1", "MILZMA_LANES": "3"},
+    "groups-streamed": dict(STREAMED, PIPELINE_BIG="1"),
+    "generic-kernel-classes": {"MILZMA_KERNEL": "generic"},
+    "always-sliced": {"MILZMA_STREAM": "0", "MILZMA_SLICE": "2"},
+}
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+@pytest.mark.parametrize("path", sorted(MATRIX))
+def test_host_pipeline_under_sanitizers(binaries, inputs, san, path):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_")}
+    env.update(MATRIX[path])
+    env.update(ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+    rounds = "1" if "PIPELINE_BIG" in MATRIX[path] else "2"
+    r = subprocess.run([binaries[san], inputs, rounds, "11"], capture_output=True, text=True, env=env, timeout=900)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("ok "), tail
+    stats = dict(kv.split("=") for kv in last.split()[1:])
+    assert int(stats["compared"]) >= 250
