@@ -59,7 +59,9 @@ struct milzma_ctx {
   int device = 0;
   std::string err;
   DevBuf units, order, results, scratch, in, out, pack, crc, flags, slice_q, slice_ctx, hostptrs;  // pack: finished outputs gathered for the download  // slice_*: queue and parked states of time-sliced launches  // flags: 64 words, one per launch in flight (last-block flags)
-  PinBuf pin_in, pin_out, pin_small, pin_lead;  // pin_lead: the units' first bytes, gathered for a streamed launch
+  PinBuf pin_in, pin_out, pin_small, pin_lead, pin_moves;  // pin_lead: the units' first bytes, gathered for a streamed launch
+  // pin_moves: move lists (milzma_move_units) -- a buffer of their own: an on-demand decode inside a batched XZ walk may regrow a parked
+  // unit while other files' walks still read the blocks' CRC parts out of pin_small (ThreadSanitizer found them sharing it)
   std::mutex mu;  // serialises GPU use by the worker threads of the batched XZ walk
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // milzma_decode_units_async: what is in flight until milzma_decode_units_wait
@@ -396,6 +398,7 @@ extern "C" void milzma_destroy(milzma_ctx* ctx) {
   pin_release(ctx->pin_out);
   pin_release(ctx->pin_small);
   pin_release(ctx->pin_lead);
+  pin_release(ctx->pin_moves);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->work_stream) (void)hipStreamDestroy(ctx->work_stream);
@@ -1227,9 +1230,9 @@ static int move_units_impl(milzma_ctx* ctx, uint32_t n, const void* d_src, const
   }
   const size_t bytes = size_t(n) * 3 * sizeof(uint64_t);
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !dev_reserve(ctx, ctx->order, std::max(bytes, ctx->order.cap)) ||
-      !pin_reserve(ctx, ctx->pin_small, bytes))
+      !pin_reserve(ctx, ctx->pin_moves, bytes))
     return MILZMA_INFRA_ERROR;
-  uint64_t* h = static_cast<uint64_t*>(ctx->pin_small.p);
+  uint64_t* h = static_cast<uint64_t*>(ctx->pin_moves.p);
   memcpy(h, src_off, size_t(n) * 8);
   memcpy(h + n, dst_off, size_t(n) * 8);
   memcpy(h + 2 * size_t(n), len, size_t(n) * 8);

@@ -188,6 +188,33 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // mutated variants (PIPELINE_MUTATIONS per file): a flipped bit, a changed byte, an inserted / removed byte, changes near the end (where an
+  // .xz file keeps its Index and footer).  Container damage is the host code's own business (compared with the oracle); a damaged payload
+  // only has to come back as SOME reference error.
+  if (const char* e = getenv("PIPELINE_MUTATIONS")) {
+    const int per = atoi(e);
+    for (int k = 0; k < 3; k++) {
+      const size_t n0 = pool[k].size();
+      for (size_t i = 0; i < n0; i++)
+        for (int v = 0; v < per; v++) {
+          Case c = pool[k][i];
+          if (c.data.size() < 8) continue;
+          const uint32_t ops = 1 + rng.below(2);
+          for (uint32_t o = 0; o < ops; o++) {
+            const bool tail = k == XZ && rng.below(2) == 0;   // (Index / footer region)
+            const size_t at = tail ? c.data.size() - 1 - rng.below(uint32_t(std::min<size_t>(c.data.size() - 1, 48))) : rng.below(uint32_t(c.data.size()));
+            switch (rng.below(4)) {
+              case 0: c.data[at] ^= uint8_t(1u << rng.below(8)); break;
+              case 1: c.data[at] = uint8_t(rng.next()); break;
+              case 2: c.data.insert(c.data.begin() + at, uint8_t(rng.below(3) ? 0 : rng.next())); break;
+              default: c.data.erase(c.data.begin() + at); break;
+            }
+          }
+          c.name += " (mutation " + std::to_string(v) + ")";
+          pool[k].push_back(std::move(c));
+        }
+    }
+  }
   milzma_ctx *ctx = nullptr, *ctx2 = nullptr;
   if (milzma_create(0, &ctx) != MILZMA_OK || milzma_create(0, &ctx2) != MILZMA_OK) {
     fprintf(stderr, "milzma_create: %s\n", milzma_last_error(nullptr));
