@@ -16,8 +16,10 @@
 #include <cstring>
 #include <functional>
 #include <future>
+#include <map>
+#include <memory>
 #include <mutex>
-#include <set>
+#include <vector>
 
 namespace {
 
@@ -33,7 +35,7 @@ struct FakeEvent {
 
 FakeStream g_null_stream;
 std::mutex g_streams_mu;
-std::set<FakeStream*> g_streams;
+std::map<FakeStream*, std::shared_ptr<FakeStream>> g_streams;   // (shared: a device-wide drain may still hold a stream another thread destroys)
 thread_local int t_device = 0;
 
 FakeStream* S(hipStream_t s) { return s ? reinterpret_cast<FakeStream*>(s) : &g_null_stream; }
@@ -57,12 +59,12 @@ void drain(FakeStream* s) {
 }
 
 void drain_all() {
-  std::set<FakeStream*> all;
+  std::vector<std::shared_ptr<FakeStream>> all;
   {
     std::lock_guard<std::mutex> lock(g_streams_mu);
-    all = g_streams;
+    for (auto& kv : g_streams) all.push_back(kv.second);
   }
-  for (FakeStream* s : all) drain(s);
+  for (auto& s : all) drain(s.get());
   drain(&g_null_stream);
 }
 
@@ -153,10 +155,11 @@ hipError_t hipMemsetD16Async(hipDeviceptr_t dst, unsigned short v, size_t count,
 }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* out, unsigned int) {
-  FakeStream* s = new FakeStream();
+  auto sp = std::make_shared<FakeStream>();
+  FakeStream* s = sp.get();
   {
     std::lock_guard<std::mutex> lock(g_streams_mu);
-    g_streams.insert(s);
+    g_streams[s] = std::move(sp);
   }
   *out = reinterpret_cast<hipStream_t>(s);
   return hipSuccess;
@@ -166,12 +169,16 @@ hipError_t hipStreamDestroy(hipStream_t stream) {
   if (!stream) return hipSuccess;
   FakeStream* s = S(stream);
   drain(s);
+  std::shared_ptr<FakeStream> last;
   {
     std::lock_guard<std::mutex> lock(g_streams_mu);
-    g_streams.erase(s);
+    auto it = g_streams.find(s);
+    if (it != g_streams.end()) {
+      last = std::move(it->second);
+      g_streams.erase(it);
+    }
   }
-  delete s;
-  return hipSuccess;
+  return hipSuccess;   // (`last` goes here, or with the last device-wide drain that holds it)
 }
 hipError_t hipStreamSynchronize(hipStream_t stream) {
   drain(S(stream));

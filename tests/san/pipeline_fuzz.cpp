@@ -268,6 +268,181 @@ int main(int argc, char** argv) {
       ok = b.verify("async xz") && ok;
     }
   }
+  // 3b. the unit-level calls a device-resident pipeline makes ("device" memory is host memory here): a caller's own GROW / move / RESUME
+  //     loop from slices that start far too small, the asynchronous halves, and the .xz pipeline milzma_xz_plan -> decode -> milzma_crc_units
+  if (ok) {
+    std::vector<const Case*> cs;
+    for (const Case& c : pool[LZMA2]) {
+      Want w = oracle_of(c);
+      if (w.r.kind == ORC_OK && w.r.out_len > 0) cs.push_back(&c);
+      orc_free(w.r.out);
+    }
+    const uint32_t n = uint32_t(cs.size());
+    std::vector<milzma_unit> units(n);
+    std::vector<orc_result> want(n);
+    size_t io = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      memset(&want[i], 0, sizeof want[i]);
+      orc_lzma2_decompress(ptr_of(cs[i]->data), cs[i]->data.size(), &want[i]);
+      memset(&units[i], 0, sizeof units[i]);
+      units[i].kind = MILZMA_KIND_LZMA2;
+      units[i].in_off = io;
+      units[i].in_len = cs[i]->data.size();
+      io += (cs[i]->data.size() + 255) & ~size_t(255);
+    }
+    std::vector<uint8_t> in(io + 512, 0);
+    for (uint32_t i = 0; i < n; i++) memcpy(in.data() + units[i].in_off, ptr_of(cs[i]->data), cs[i]->data.size());
+    // slices of 512 bytes to begin with; grown by 3x per round
+    std::vector<uint8_t> out;
+    size_t oo = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      units[i].out_off = oo;
+      units[i].out_cap = 512;
+      oo += 512;
+    }
+    out.assign(oo + 512, 0);
+    std::vector<milzma_result> res(n);
+    uint32_t flags = MILZMA_DECODE_GROW;
+    int rounds_done = 0;
+    for (;; rounds_done++) {
+      if (milzma_decode_units_ex(ctx, units.data(), n, in.data(), out.data(), res.data(), nullptr, flags) != MILZMA_OK) {
+        printf("INFRA decode_units_ex: %s\n", milzma_last_error(ctx));
+        ok = false;
+        break;
+      }
+      std::vector<uint64_t> so, dof, ln;
+      std::vector<uint8_t> bigger;
+      size_t total = 0;
+      std::vector<milzma_unit> next = units;
+      bool any = false;
+      for (uint32_t i = 0; i < n; i++) {
+        const bool parked = res[i].status == MILZMA_ST_OUT_FULL && res[i].err_a == MILZMA_PARKED;
+        any = any || parked;
+        next[i].out_off = total;
+        next[i].out_cap = parked ? units[i].out_cap * 3 : units[i].out_cap;
+        so.push_back(units[i].out_off);
+        dof.push_back(total);
+        ln.push_back(res[i].out_len < units[i].out_cap ? res[i].out_len : units[i].out_cap);
+        total += size_t(next[i].out_cap);
+      }
+      if (!any) break;
+      bigger.assign(total + 512, 0);
+      if (milzma_move_units(ctx, n, out.data(), so.data(), bigger.data(), dof.data(), ln.data(), nullptr) != MILZMA_OK) {
+        printf("INFRA move_units: %s\n", milzma_last_error(ctx));
+        ok = false;
+        break;
+      }
+      out.swap(bigger);
+      units = next;
+      flags = MILZMA_DECODE_RESUME;
+    }
+    for (uint32_t i = 0; i < n && ok; i++) {
+      g_cases++;
+      g_compared++;
+      if (res[i].status != MILZMA_ST_OK || res[i].out_len != want[i].out_len || memcmp(out.data() + units[i].out_off, want[i].out, want[i].out_len) != 0) {
+        printf("MISMATCH unit %u (%s) after %d grow rounds: status %u len %" PRIu64 " (want %zu)\n", i, cs[i]->name.c_str(), rounds_done, res[i].status,
+               res[i].out_len, want[i].out_len);
+        ok = false;
+      }
+    }
+    // the asynchronous halves + the CRCs of what was decoded
+    if (ok && n) {
+      std::vector<milzma_result> r2(n);
+      std::vector<uint32_t> c32(n);
+      std::vector<uint64_t> c64(n);
+      if (milzma_decode_units_async(ctx, units.data(), n, in.data(), out.data(), nullptr) != MILZMA_OK ||
+          milzma_decode_units_async(ctx, units.data(), n, in.data(), out.data(), nullptr) != MILZMA_INFRA_ERROR ||   // (a second one is refused)
+          milzma_decode_units_wait(ctx, r2.data()) != MILZMA_OK ||
+          milzma_crc_units(ctx, units.data(), n, out.data(), r2.data(), c32.data(), c64.data(), nullptr) != MILZMA_OK) {
+        printf("INFRA async / crc: %s\n", milzma_last_error(ctx));
+        ok = false;
+      }
+      for (uint32_t i = 0; i < n && ok; i++)
+        if (r2[i].status != MILZMA_ST_OK || c32[i] != orc_crc32(want[i].out, want[i].out_len) || c64[i] != orc_crc64(want[i].out, want[i].out_len)) {
+          printf("MISMATCH unit %u: CRCs of the device-side digest\n", i);
+          ok = false;
+        }
+    }
+    for (auto& w : want) orc_free(w.out);
+    // milzma_xz_plan: the Index of a good file -> one unit per block; decoded, every block's bytes where the plan put them
+    for (const Case& c : pool[XZ]) {
+      if (!ok) break;
+      Want w = oracle_of(c);
+      uint32_t nu = 0, check = 0;
+      std::vector<milzma_unit> pu(256);
+      if (w.r.kind == ORC_OK && milzma_xz_plan(ptr_of(c.data), c.data.size(), pu.data(), 256, &nu, &check) == MILZMA_OK && nu && nu <= 256) {
+        size_t cap = 0;
+        for (uint32_t k = 0; k < nu; k++) {
+          pu[k].out_off = cap;
+          cap += size_t(pu[k].out_cap);
+        }
+        std::vector<uint8_t> fin(c.data.size() + 512, 0), fout(cap + 512, 0);
+        memcpy(fin.data(), ptr_of(c.data), c.data.size());
+        std::vector<milzma_result> pr(nu);
+        if (milzma_decode_units(ctx, pu.data(), nu, fin.data(), fout.data(), pr.data(), nullptr) != MILZMA_OK) {
+          printf("INFRA planned decode: %s\n", milzma_last_error(ctx));
+          ok = false;
+        }
+        size_t at = 0;
+        for (uint32_t k = 0; k < nu && ok; k++) {
+          g_cases++;
+          g_compared++;
+          if (pr[k].status != MILZMA_ST_OK || at + pr[k].out_len > w.r.out_len || memcmp(fout.data() + pu[k].out_off, w.r.out + at, size_t(pr[k].out_len)) != 0) {
+            printf("MISMATCH planned block %u of %s\n", k, c.name.c_str());
+            ok = false;
+          }
+          at += size_t(pr[k].out_len);
+        }
+        if (ok && at != w.r.out_len) {
+          printf("MISMATCH planned blocks of %s: %zu bytes of %zu\n", c.name.c_str(), at, w.r.out_len);
+          ok = false;
+        }
+      }
+      orc_free(w.r.out);
+    }
+  }
+  // 3c. application threads of their own, a context each, all at once (the result-buffer pool, the one-streamed-launch-per-device rule)
+  if (ok) {
+    std::vector<std::thread> th;
+    std::vector<int> good(3, 1);
+    for (int t = 0; t < 3; t++)
+      th.emplace_back([&, t] {
+        milzma_ctx* c3 = nullptr;
+        if (milzma_create(0, &c3) != MILZMA_OK) {
+          good[t] = 0;
+          return;
+        }
+        Rng r2{0xABCDEF12345ull + uint64_t(t)};
+        for (int it = 0; it < 2; it++) {
+          const Kind k = Kind((t + it) % 3);
+          Batch b;
+          for (uint32_t i = 0; i < 25; i++) b.add(&pool[k][r2.below(uint32_t(pool[k].size()))]);
+          b.prepare();
+          const uint32_t n = uint32_t(b.cases.size());
+          const int rc = k == LZMA    ? lzma_batch(c3, n, b.ins.data(), b.lens.data(), b.outs.data())
+                         : k == LZMA2 ? milzma_lzma2_decompress_batch(c3, n, b.ins.data(), b.lens.data(), b.outs.data())
+                                      : milzma_xz_decompress_batch(c3, n, b.ins.data(), b.lens.data(), b.outs.data());
+          if (rc == MILZMA_INFRA_ERROR) good[t] = 0;
+          for (size_t i = 0; i < b.cases.size(); i++) {   // (check() counts in globals: compared here, by hand)
+            Want w = oracle_of(*b.cases[i]);
+            const milzma_output& o = b.outs[i];
+            if (w.faithful && !(o.kind == w.r.kind && strcmp(o.msg, w.r.msg) == 0 && o.len == w.r.out_len &&
+                                (o.len == 0 || memcmp(o.data, w.r.out, o.len) == 0) && o.in_consumed == w.r.in_consumed))
+              good[t] = 0;
+            orc_free(w.r.out);
+            milzma_free(o.data);
+          }
+        }
+        milzma_destroy(c3);
+      });
+    for (auto& x : th) x.join();
+    for (int t = 0; t < 3; t++)
+      if (!good[t]) {
+        printf("MISMATCH in application thread %d\n", t);
+        ok = false;
+      }
+    g_cases += 150;
+  }
   // 4. a call large enough to be cut into groups over lanes (>= 8192 units): tiny files, many times
   if (ok && getenv("PIPELINE_BIG")) {
     Batch b;
