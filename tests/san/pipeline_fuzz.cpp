@@ -270,7 +270,8 @@ int main(int argc, char** argv) {
   }
   // 3b. the unit-level calls a device-resident pipeline makes ("device" memory is host memory here): a caller's own GROW / move / RESUME
   //     loop from slices that start far too small, the asynchronous halves, and the .xz pipeline milzma_xz_plan -> decode -> milzma_crc_units
-  if (ok) {
+  //     (units of the generic kernel cannot be parked: they come back with a plain OUT_FULL and start over -- another loop, not this one)
+  if (ok && !(getenv("MILZMA_KERNEL") && !strcmp(getenv("MILZMA_KERNEL"), "generic"))) {
     std::vector<const Case*> cs;
     for (const Case& c : pool[LZMA2]) {
       Want w = oracle_of(c);
