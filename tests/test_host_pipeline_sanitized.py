@@ -68,7 +68,7 @@ def binaries(tmp_path_factory):
     if not os.path.exists(CLANG):
         pytest.skip("no clang with sanitizer runtimes in this image")
     out = str(tmp_path_factory.mktemp("pipeline_build"))
-    r = subprocess.run(["make", "-C", SAN, "-s", "OUT=" + out, out + "/pipeline_asan", out + "/pipeline_tsan"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", SAN, "-s", "-j2", "OUT=" + out, out + "/pipeline_asan", out + "/pipeline_tsan"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return {"asan": out + "/pipeline_asan", "tsan": out + "/pipeline_tsan"}
 
