@@ -369,6 +369,7 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   }
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
       !hip_ok(nullptr, hipEventCreate(&ctx->ev1), "hipEventCreate")) {
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);   // (the first one may exist: fault injection found it left behind)
     delete ctx;
     return MILZMA_INFRA_ERROR;
   }

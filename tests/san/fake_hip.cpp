@@ -68,6 +68,13 @@ void drain_all() {
   drain(&g_null_stream);
 }
 
+// Fault injection (pipeline_fuzz.cpp, PIPELINE_FAULTS): the n-th fallible runtime call from now on fails.
+std::atomic<long> g_calls{0}, g_fail_at{-1};
+bool fails_now() {
+  const long k = g_calls.fetch_add(1) + 1;
+  return k == g_fail_at.load();
+}
+
 int device_count() {
   const char* e = getenv("FAKE_HIP_DEVICES");
   const int n = e ? atoi(e) : 1;
@@ -78,6 +85,12 @@ int device_count() {
 
 // (tests/san/fake_kernels.cpp queues the stand-in kernels through this)
 void fake_hip_enqueue(hipStream_t stream, std::function<void()> fn) { enqueue(S(stream), std::move(fn)); }
+void fake_hip_fail_at(long n) {
+  g_calls.store(0);
+  g_fail_at.store(n);
+}
+long fake_hip_calls() { return g_calls.load(); }
+bool fake_hip_launch_fails() { return fails_now(); }
 
 extern "C" {
 
@@ -103,6 +116,8 @@ hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "fake HIP error"; }
 
 hipError_t hipMalloc(void** p, size_t n) {
+  *p = nullptr;
+  if (fails_now()) return hipErrorOutOfMemory;
   *p = malloc(n ? n : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
@@ -112,6 +127,8 @@ hipError_t hipFree(void* p) {
   return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
+  *p = nullptr;
+  if (fails_now()) return hipErrorOutOfMemory;
   *p = malloc(n ? n : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
@@ -131,17 +148,20 @@ hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
 }
 
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+  if (fails_now()) return hipErrorUnknown;
   drain(&g_null_stream);
   if (n) memmove(dst, src, n);
   return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t stream) {
+  if (fails_now()) return hipErrorUnknown;
   enqueue(S(stream), [=] {
     if (n) memmove(dst, src, n);
   });
   return hipSuccess;
 }
 hipError_t hipMemcpyPeer(void* dst, int, const void* src, int, size_t n) {
+  if (fails_now()) return hipErrorUnknown;
   drain(&g_null_stream);
   if (n) memmove(dst, src, n);
   return hipSuccess;
@@ -155,6 +175,7 @@ hipError_t hipMemsetD16Async(hipDeviceptr_t dst, unsigned short v, size_t count,
 }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* out, unsigned int) {
+  if (fails_now()) return hipErrorOutOfMemory;
   auto sp = std::make_shared<FakeStream>();
   FakeStream* s = sp.get();
   {
@@ -190,6 +211,7 @@ hipError_t hipDeviceSynchronize(void) {
 }
 
 hipError_t hipEventCreateWithFlags(hipEvent_t* out, unsigned) {
+  if (fails_now()) return hipErrorOutOfMemory;
   *out = reinterpret_cast<hipEvent_t>(new FakeEvent());
   return hipSuccess;
 }

@@ -20,6 +20,7 @@
 #include "lzma_oracle.h"
 
 void fake_hip_enqueue(hipStream_t stream, std::function<void()> fn);
+bool fake_hip_launch_fails();
 extern "C" uint32_t milzma_crc32(const uint8_t* p, size_t n);
 extern "C" uint64_t milzma_crc64(const uint8_t* p, size_t n);
 
@@ -136,11 +137,13 @@ namespace milzma {
 
 hipError_t launch_generic(LitClass, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                           milzma_result* d_results, uint16_t*, uint32_t, hipStream_t stream) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), true); });
   return hipSuccess;
 }
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
                        hipStream_t stream, uint32_t, uint32_t*, const uint8_t* d_slab, uint32_t) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   const bool has_slab = d_slab != nullptr;
   fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), has_slab); });
   return hipSuccess;
@@ -152,6 +155,7 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
                               milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool grow,
                               uint32_t span_bytes, uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready,
                               const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   Streamed st;
   st.span = span_bytes;
   st.n_spans = n_spans;
@@ -168,6 +172,7 @@ uint32_t stream_lead_bytes(uint32_t in_len) {
   return q4 > 4096u ? q4 : 4096u;   // (the real kernels: a quarter, at least 128 KiB -- small here, so that small files have a second part)
 }
 hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   fake_hip_enqueue(stream, [=] {
     for (uint32_t i = 0; i < n; i++)
       if (d_offs[2 * size_t(n) + i]) memmove(d_dst + d_offs[size_t(n) + i], d_src + d_offs[i], size_t(d_offs[2 * size_t(n) + i]));
@@ -177,6 +182,7 @@ hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_
 // crc_units.hip.h: 64 chunks per unit, the partial CRCs of each, folded by host.cpp's crc_fold
 hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results, void* d_parts,
                             hipStream_t stream) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   fake_hip_enqueue(stream, [=] {
     uint8_t* parts = static_cast<uint8_t*>(d_parts);
     for (uint32_t u = 0; u < n; u++) {

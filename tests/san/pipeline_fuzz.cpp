@@ -21,6 +21,9 @@
 #include "lzma_oracle.h"
 #include "milzma.h"
 
+void fake_hip_fail_at(long n);   // tests/san/fake_hip.cpp: the n-th fallible runtime call from now on fails (-1: none)
+long fake_hip_calls();
+
 namespace {
 
 struct Rng {
@@ -214,6 +217,57 @@ int main(int argc, char** argv) {
           pool[k].push_back(std::move(c));
         }
     }
+  }
+  // PIPELINE_FAULTS=K: fault injection instead of the stages below.  One batch per entry point, K times over, the n-th fallible runtime
+  // call (allocation, copy, stream / event creation, kernel launch) failing in run n: whatever fails, every file comes back either as the
+  // oracle has it or with an infrastructure error and a text -- never as an empty success, never with a crash, a hang or a leak.
+  if (const char* e = getenv("PIPELINE_FAULTS")) {
+    const long upto = atol(e);
+    long worst = 0, infra_files = 0, good_files = 0;
+    for (int k = 0; k < 3; k++) {
+      Batch b;
+      for (uint32_t i = 0; i < 8; i++) b.add(&pool[k][rng.below(uint32_t(pool[k].size()))]);
+      long last = upto;   // (after the fault-free run: no further than the calls a batch makes)
+      for (long n = 0; n <= last; n++) {
+        milzma_ctx* c = nullptr;
+        fake_hip_fail_at(n == 0 ? -1 : n);
+        if (milzma_create(0, &c) != MILZMA_OK) continue;   // (creation itself failed: reported, nothing to run)
+        b.prepare();
+        const uint32_t cnt = uint32_t(b.cases.size());
+        const int rc = k == LZMA    ? lzma_batch(c, cnt, b.ins.data(), b.lens.data(), b.outs.data())
+                       : k == LZMA2 ? milzma_lzma2_decompress_batch(c, cnt, b.ins.data(), b.lens.data(), b.outs.data())
+                                    : milzma_xz_decompress_batch(c, cnt, b.ins.data(), b.lens.data(), b.outs.data());
+        worst = std::max(worst, fake_hip_calls());
+        if (n == 0) last = std::min(upto, fake_hip_calls() + 2);
+        fake_hip_fail_at(-1);
+        for (size_t i = 0; i < b.cases.size(); i++) {
+          const milzma_output& o = b.outs[i];
+          if (o.kind == MILZMA_INFRA_ERROR) {
+            infra_files++;
+            if (o.msg[0] == 0 || (o.data == nullptr && o.len != 0)) {
+              printf("MISMATCH fault %ld, %s: an infrastructure error without a text: msg '%s' data %p len %zu rc %d, context says '%s'\n", n,
+                     b.cases[i]->name.c_str(), o.msg, (void*)o.data, o.len, rc, milzma_last_error(c));
+              return 1;
+            }
+          } else {
+            good_files++;
+            if (!check(*b.cases[i], o, "batch under fault injection")) {
+              printf("  (fault at call %ld of entry point %d)\n", n, k);
+              return 1;
+            }
+          }
+          milzma_free(o.data);
+        }
+        milzma_destroy(c);
+      }
+    }
+    const size_t pooled = milzma_pool_trim(0);
+    if (pooled != 0) {
+      printf("MISMATCH: %zu bytes still pooled after milzma_pool_trim(0)\n", pooled);
+      return 1;
+    }
+    printf("ok faults=%ld calls_per_batch<=%ld files_with_infra_error=%ld files_decoded=%ld compared=%" PRIu64 "\n", upto, worst, infra_files, good_files, g_compared);
+    return 0;
   }
   milzma_ctx *ctx = nullptr, *ctx2 = nullptr;
   if (milzma_create(0, &ctx) != MILZMA_OK || milzma_create(0, &ctx2) != MILZMA_OK) {
