@@ -880,12 +880,23 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
   ctx->pending = false;
   if (n == 0) return MILZMA_OK;
   hipStream_t stream = ctx->pend_stream;
+  // Whatever fails from here on: nothing of this batch may still be running when the caller is told (a kernel of a promotion round, a
+  // copy into the caller's results) -- it would write memory the caller is free to release (fault injection found a launch outliving
+  // its failed call).  The device is drained first, the error text kept.
+  const auto bail = [&]() {
+    const std::string why = ctx->err;
+    (void)hipStreamSynchronize(stream);
+    (void)hipGetLastError();
+    ctx->err = why;
+    ctx->ev_used = 0;
+    return MILZMA_INFRA_ERROR;
+  };
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") || !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") ||
       !collect_kernel_ms(ctx) ||
       !hip_ok(ctx, hipMemcpyAsync(ctx->pin_results.p, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
               "D2H results") ||
       !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
-    return MILZMA_INFRA_ERROR;
+    return bail();
   memcpy(results, ctx->pin_results.p, size_t(n) * sizeof(milzma_result));
 
   // Promotions: LZMA2 units whose chunks switched to properties outside their class's reach run
@@ -906,13 +917,13 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
                                hipMemcpyHostToDevice, stream),
                 "H2D order") ||
         !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))  // (`again` is pageable and about to go away)
-      return MILZMA_INFRA_ERROR;
-    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream, (ctx->pend_flags & MILZMA_DECODE_GROW) != 0)) return MILZMA_INFRA_ERROR;
+      return bail();
+    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream, (ctx->pend_flags & MILZMA_DECODE_GROW) != 0)) return bail();
     if (!hip_ok(ctx,
                 hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
                 "D2H results") ||
         !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize") || !collect_kernel_ms(ctx))
-      return MILZMA_INFRA_ERROR;
+      return bail();
   }
   if (ctx->pend_flags & MILZMA_DECODE_GROW) {
     bool any = false;
@@ -1176,8 +1187,22 @@ void crc_fold(const uint8_t* parts, uint64_t len, uint32_t* crc32, uint64_t* crc
 
 }  // namespace
 
+static int crc_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_out, const milzma_result* results,
+                          uint32_t* crc32, uint64_t* crc64, void* hip_stream);
+
 extern "C" int milzma_crc_units(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_out,
                                 const milzma_result* results, uint32_t* crc32, uint64_t* crc64, void* hip_stream) {
+  if (ctx) ctx->err.clear();
+  try {
+    return crc_units_impl(ctx, units, n, d_out, results, crc32, crc64, hip_stream);
+  } catch (const std::exception& e) {   // (std::bad_alloc from the staging vector: never across the C ABI)
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+static int crc_units_impl(milzma_ctx* ctx, const milzma_unit* units, uint32_t n, const void* d_out, const milzma_result* results,
+                          uint32_t* crc32, uint64_t* crc64, void* hip_stream) {
   if (!ctx) return MILZMA_INFRA_ERROR;
   if (n == 0) return MILZMA_OK;
   if (!units || !results) {
@@ -1200,8 +1225,12 @@ extern "C" int milzma_crc_units(milzma_ctx* ctx, const milzma_unit* units, uint3
                                static_cast<const milzma_result*>(ctx->results.p), ctx->crc.p, stream),
               "crc kernel launch") ||
       !hip_ok(ctx, hipMemcpyAsync(parts.data(), ctx->crc.p, parts.size(), hipMemcpyDeviceToHost, stream), "D2H crc parts") ||
-      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize")) {
+    const std::string why = ctx->err;   // (what was queued still reads the caller's arrays and writes `parts`: drained before either goes)
+    (void)hipStreamSynchronize(stream);
+    ctx->err = why;
     return MILZMA_INFRA_ERROR;
+  }
   for (uint32_t i = 0; i < n; i++) {
     uint32_t a = 0;
     uint64_t b = 0;
@@ -1240,8 +1269,12 @@ static int move_units_impl(milzma_ctx* ctx, uint32_t n, const void* d_src, const
   if (!hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h, bytes, hipMemcpyHostToDevice, stream), "H2D move list") ||
       !hip_ok(ctx, launch_move_units(static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), static_cast<const uint64_t*>(ctx->order.p), n, stream),
               "move kernel launch") ||
-      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))
+      !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize")) {
+    const std::string why = ctx->err;   // (a queued move reads and writes the caller's buffers: drained before the caller is told)
+    (void)hipStreamSynchronize(stream);
+    ctx->err = why;
     return MILZMA_INFRA_ERROR;
+  }
   return MILZMA_OK;
 }
 

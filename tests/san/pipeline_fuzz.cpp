@@ -261,6 +261,92 @@ int main(int argc, char** argv) {
         milzma_destroy(c);
       }
     }
+    // ... and the multi-device calls (FAKE_HIP_DEVICES / MILZMA_MULTI_REPLICAS): a whole-file batch, and the one-ingest-point unit call
+    if (getenv("PIPELINE_FAULTS_MULTI")) {
+      for (int form = 0; form < 2; form++) {
+        Batch b;
+        for (uint32_t i = 0; i < 9; i++) b.add(&pool[form == 0 ? XZ : LZMA2][rng.below(uint32_t(pool[form == 0 ? XZ : LZMA2].size()))]);
+        // (form 1: LZMA2 units that decode, packed into one "device" buffer)
+        std::vector<const Case*> cs;
+        std::vector<orc_result> want;
+        std::vector<milzma_unit> units;
+        std::vector<uint8_t> in;
+        size_t io = 0, oo = 0;
+        if (form == 1) {
+          for (const Case* c : b.cases) {
+            Want w = oracle_of(*c);
+            if (w.r.kind == ORC_OK) {
+              milzma_unit u;
+              memset(&u, 0, sizeof u);
+              u.kind = MILZMA_KIND_LZMA2;
+              u.in_off = io;
+              u.in_len = c->data.size();
+              u.out_off = oo;
+              u.out_cap = w.r.out_len + 32;
+              io += (c->data.size() + 255) & ~size_t(255);
+              oo += size_t(u.out_cap);
+              units.push_back(u);
+              cs.push_back(c);
+              want.push_back(w.r);
+            } else {
+              orc_free(w.r.out);
+            }
+          }
+          in.assign(io + 512, 0);
+          for (size_t i = 0; i < cs.size(); i++) memcpy(in.data() + units[i].in_off, ptr_of(cs[i]->data), cs[i]->data.size());
+        }
+        long last = upto;
+        for (long n = 0; n <= last; n++) {
+          milzma_multi* m = nullptr;
+          fake_hip_fail_at(n == 0 ? -1 : n);
+          if (milzma_multi_create(0, &m) != MILZMA_OK) continue;
+          if (form == 0) {
+            b.prepare();
+            const int rc = milzma_multi_xz_decompress_batch(m, uint32_t(b.cases.size()), b.ins.data(), b.lens.data(), b.outs.data());
+            if (n == 0) last = std::min(upto, fake_hip_calls() + 2);
+            fake_hip_fail_at(-1);
+            for (size_t i = 0; i < b.cases.size(); i++) {
+              const milzma_output& o = b.outs[i];
+              if (o.kind == MILZMA_INFRA_ERROR) {
+                infra_files++;
+                if (o.msg[0] == 0) {
+                  printf("MISMATCH multi fault %ld, %s: an infrastructure error without a text (rc %d, '%s')\n", n, b.cases[i]->name.c_str(), rc, milzma_multi_last_error(m));
+                  return 1;
+                }
+              } else {
+                good_files++;
+                if (!check(*b.cases[i], o, "multi batch under fault injection")) return 1;
+              }
+              milzma_free(o.data);
+            }
+          } else if (!units.empty()) {
+            std::vector<uint8_t> out(oo + 512, 0xAA);
+            std::vector<milzma_result> res(units.size());
+            const int rc = milzma_multi_decode_units_rooted(m, 0, units.data(), uint32_t(units.size()), in.data(), out.data(), res.data());
+            if (n == 0) last = std::min(upto, fake_hip_calls() + 2);
+            fake_hip_fail_at(-1);
+            if (rc == MILZMA_OK) {
+              for (size_t i = 0; i < units.size(); i++) {
+                good_files++;
+                if (res[i].status != MILZMA_ST_OK || res[i].out_len != want[i].out_len ||
+                    (want[i].out_len && memcmp(out.data() + units[i].out_off, want[i].out, want[i].out_len) != 0)) {
+                  printf("MISMATCH rooted call under fault %ld: unit %zu (%s) status %u\n", n, i, cs[i]->name.c_str(), res[i].status);
+                  return 1;
+                }
+              }
+            } else {
+              infra_files += long(units.size());
+              if (milzma_multi_last_error(m)[0] == 0) {
+                printf("MISMATCH rooted call under fault %ld: failed without a text\n", n);
+                return 1;
+              }
+            }
+          }
+          milzma_multi_destroy(m);
+        }
+        for (auto& w : want) orc_free(w.out);
+      }
+    }
     const size_t pooled = milzma_pool_trim(0);
     if (pooled != 0) {
       printf("MISMATCH: %zu bytes still pooled after milzma_pool_trim(0)\n", pooled);

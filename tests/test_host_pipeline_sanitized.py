@@ -116,14 +116,16 @@ def test_host_pipeline_under_sanitizers(binaries, inputs, san, path):
     assert int(stats["compared"]) >= 200
 
 
-@pytest.mark.parametrize("path", ["default", "streamed"])
+@pytest.mark.parametrize("path", ["default", "streamed", "multi-two-devices"])
 def test_host_pipeline_fault_injection(binaries, inputs, path):
     """Every fallible runtime call of a batch -- allocations, copies, stream and event creation, kernel launches: about a hundred per call --
     fails once (tests/san/fake_hip.cpp: fake_hip_fail_at), one run per call and entry point.  Whatever fails, every file comes back either as
     the oracle has it or with an infrastructure error and a text; no crash, no hang (the waves' input-ready word is set on failed uploads
     too), and LeakSanitizer finds nothing left behind (it found an event leaked by milzma_create's own failure path)."""
     env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_")}
-    env.update(MATRIX[path])
+    # (multi-two-devices: also the multi-device whole-file batch and the one-ingest-point unit call -- there fault injection found a
+    #  launch still writing the caller's buffer after its failed call had returned: the wait half drains the device on every way out now)
+    env.update(MATRIX.get(path, {"FAKE_HIP_DEVICES": "2", "PIPELINE_FAULTS_MULTI": "1"}))
     env.update(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", PIPELINE_FAULTS="120")
     r = subprocess.run([binaries["asan"], inputs, "1", "5"], capture_output=True, text=True, env=env, timeout=900)
     tail = (r.stdout + r.stderr)[-4000:]
