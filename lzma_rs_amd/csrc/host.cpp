@@ -700,6 +700,13 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
             ctx->stream_active = true;
           }
         }
+        // A streamed launch whose input goes up in two parts waits for the ready word before it reads beyond the units' leads; a launch
+        // that could not be made a streamed one would read what is not there yet (its results would be thrown away -- the caller falls
+        // back to the classic rounds -- but it would run on garbage beside the upload): not launched at all.
+        if (want_stream && ctx->stream_in_host && !ctx->stream_active) {
+          ctx->err = "the streamed launch could not be set up";
+          return false;
+        }
       }
     }
     const hipError_t le = sliced
@@ -1494,7 +1501,14 @@ bool upload_rest(milzma_ctx* ctx, uint8_t* hin, const std::vector<size_t>& bound
     if (hi > lo)
       ok = hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->in.p) + lo, hin + lo, hi - lo, hipMemcpyHostToDevice, ctx->copy_stream), "H2D input");
   }
-  ok = ok && hip_ok(ctx, hipStreamSynchronize(ctx->copy_stream), "hipStreamSynchronize");
+  // (drained whatever became of the pieces: the ones that were queued write ctx->in, which whoever runs next -- the classic rounds, a file
+  //  decoded on its own -- is about to use; found by ThreadSanitizer under fault injection)
+  const std::string why = ctx->err;
+  const bool drained = hipStreamSynchronize(ctx->copy_stream) == hipSuccess;
+  if (!ok)
+    ctx->err = why;
+  else if (!drained)
+    ok = hip_ok(ctx, hipErrorUnknown, "hipStreamSynchronize");
   // (ready also when a copy failed: the waves must not wait for ever -- the caller fails the call)
   __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 1u, __ATOMIC_RELEASE);
   return ok;
