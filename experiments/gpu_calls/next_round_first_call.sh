@@ -1,49 +1,21 @@
 #!/bin/bash
-# What round 3 ran out of GPU minutes for; meant to be the first call of the next round (about 10 minutes):
-#  1. PMC passes of the CURRENT kernel source for configs[1] and configs[2] (each pass under its own timeout, up to 3 attempts: rocprofv3
-#     --pmc hangs about every other time on this pool), profiles/r03_pmc_*.json rewritten for this hash (they carry an `also_valid_for`
-#     attestation until then);
-#  2. an alternating A/B of the model registers pinned to v20..v54 (MILZMA_GEN_PINV=20; one sample in round 3 said -0.9 %):
-#  3. the same for the split literal table (MILZMA_GEN_LITSPLIT=1: two scalar shifts less per literal-row swap; bit-exact on the emulator,
-#     -0.14 scalar instructions per byte on text, -1.74 on random data), on text and on random data.
-#  4. FIVE waves per SIMD: the loop generated with all its registers below v96 and the kernel built for 5 waves per SIMD compiles to 96 VGPRs /
-#     occupancy 5, 7 KiB LDS (round 3; bit-exact; 5120 streams in one round: 18.16 GB/s, +2.9 % chip throughput).  Here: the GPU suite on
-#     it and the large-batch figures with the time-sliced launch on 5120 persistent waves.  Then the time-sliced launch runs 5120 persistent waves: the decision chain's micro-benchmark says +11 % for
-#     batches of >= 5120 streams (nothing for 4096).  GPU suite on the variant first, then 4096 / 8192 / 32768 streams against the shipped library.
-#     Build the variants first:  python3 tools/build_variants.py "pinv20:PINV=20" "litsplit:LITSPLIT=1" "w5:VBASE=40,PINV=1,VROW8=7,NOPB4=1:+-DMILZMA_WAVES_PER_SIMD=5"
+# What round 4 ran out of GPU minutes for; meant to be the first call of the next round (about 6 minutes):
+#  1. the whole GPU suite on the final host library.  After the suite's last full run (107 passed, experiments/gpu_calls/r4_last.sh) host.cpp
+#     still changed: units decoded again in another launch class are fetched from the device after a streamed launch, an on-demand .xz block
+#     no longer copies over its successors' places, move lists have a page-locked buffer of their own, the wait half / milzma_crc_units /
+#     milzma_move_units drain the device on every failure path, the second-part upload drains its copy stream whatever happened, a launch
+#     that cannot be made a streamed one is not launched on incomplete input.  On the GPU these ran: the streamed fuzz (12 600 cases,
+#     profiles/r04_parity_fuzz.txt) and 40 tests of the streamed / .xz / growable paths; the rest only on the CPU harness
+#     (tests/test_host_pipeline_sanitized.py).
+#  2. the differential fuzz with every batch through the streamed launch, a few more seeds;
+#  3. the whole-file calls and the default bench line (the kernel sources are unchanged: profiles/r04_pmc_*.json stay valid as long as
+#     bench.kernel_source_hash() says 01a4e6eafd106006).
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=gpurun_out/next_pmc; rm -rf $O; mkdir -p $O
-pass() {  # cfg index counters...
-  cfg=$1; i=$2; shift 2
-  for attempt in 1 2 3; do
-    rm -rf $O/$cfg/pass_$i
-    timeout 110 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$cfg/pass_$i -- python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none > $O/${cfg}_pass_$i.log 2>&1
-    rc=$?
-    n=$(find $O/$cfg/pass_$i -name "*counter_collection.csv" 2>/dev/null | wc -l)
-    echo "$cfg pass $i attempt $attempt rc=$rc csv=$n"
-    [ "$n" -gt 0 ] && break
-  done
-}
-for cfg in lzma64k dict8m; do
-  pass $cfg 1 FETCH_SIZE
-  pass $cfg 2 WRITE_SIZE
-  pass $cfg 3 SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY
-  python tools/make_pmc_profile.py $cfg $O/$cfg $O/r03_pmc_$cfg.json > /dev/null 2>&1 && cp $O/r03_pmc_$cfg.json profiles/
+O=gpurun_out/next_first; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $O/suite.txt
+for seed in 81 82; do
+  MILZMA_STREAM_MIN=1,1,1 timeout 120 python experiments/parity_fuzz.py --seed $seed --rounds 4 2>&1 | tail -1 | tee -a $O/fuzz_streamed.txt
 done
-rm -rf $O/*/pass_*/*/*.db 2>/dev/null
-V=lzma_rs_amd/variants/libmilzma_pinv20.so
-[ -f $V ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $V lzma_rs_amd/libmilzma.so $V | tee gpurun_out/next_pinv_ab.txt
-W=lzma_rs_amd/variants/libmilzma_litsplit.so
-[ -f $W ] && python experiments/ab_bench.py --steps 4 lzma_rs_amd/libmilzma.so $W lzma_rs_amd/libmilzma.so $W | tee gpurun_out/next_litsplit_ab.txt
-[ -f $W ] && python experiments/ab_bench.py --steps 3 --kind random lzma_rs_amd/libmilzma.so $W | tee -a gpurun_out/next_litsplit_ab.txt
-X=$PWD/lzma_rs_amd/variants/libmilzma_w5.so
-if [ -f $X ]; then
-  MILZMA_LIB=$X timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-  for n in 4096 8192 32768; do
-    for lib in lzma_rs_amd/libmilzma.so $X; do
-      MILZMA_LIB=$PWD/${lib#$PWD/} timeout 300 python bench.py --streams $n --steps 2 --warmup 1 --no-cpu-baseline --other-configs none 2>/dev/null | python -c "
-import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$n streams', '$lib'.split('/')[-1], l['value'], 'GB/s', l['ms_per_step'], 'ms', l['bit_exact'])"
-    done
-  done | tee gpurun_out/next_w5.txt
-fi
+( BATCH_VERIFY_ALL=1 timeout 200 python experiments/batch_api_bench.py 4096 512 lzma 0 2>&1 | grep -E "run|verified";
+  BATCH_VERIFY_ALL=1 timeout 200 python experiments/batch_api_bench.py 1024 64 xz 0 2>&1 | grep -E "run|verified" ) | tee $O/batch_api.txt
+timeout 600 python bench.py > $O/bench_default.json 2>$O/bench_default.err; tail -c 300 $O/bench_default.json
