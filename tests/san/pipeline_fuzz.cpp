@@ -593,6 +593,57 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < 8192 + 300; i++) b.add(i % 7 == 0 ? &pool[LZMA][rng.below(uint32_t(pool[LZMA].size()))] : tiny);
     ok = run_batch(ctx, LZMA, b, "lzma batch in groups") && ok;
   }
+  // 4b. decompress::Options on .lzma files (src/decode/options.rs): the three UnpackedSize modes with and without a provided size, a memory
+  //     limit that does not bite -- through the batch call (one option set per batch) and the single-file call
+  for (int v = 0; v < 6 && ok; v++) {
+    milzma_options mo;
+    orc_options oo;
+    milzma_default_options(&mo);
+    orc_default_options(&oo);
+    mo.unpacked_size_mode = oo.unpacked_size_mode = v % 3;
+    mo.provided_is_some = oo.provided_is_some = v >= 3;
+    mo.provided = oo.provided = 20000;                   // (right for some files, wrong for most)
+    mo.memlimit_is_some = oo.memlimit_is_some = v & 1;
+    mo.memlimit = oo.memlimit = uint64_t(1) << 30;
+    Batch b;
+    for (uint32_t i = 0; i < 16; i++) b.add(&pool[LZMA][rng.below(uint32_t(pool[LZMA].size()))]);
+    b.prepare();
+    if (milzma_lzma_decompress_batch(ctx, uint32_t(b.cases.size()), b.ins.data(), b.lens.data(), &mo, b.outs.data()) == MILZMA_INFRA_ERROR) {
+      printf("INFRA lzma batch with options: %s\n", milzma_last_error(ctx));
+      ok = false;
+      break;
+    }
+    for (size_t i = 0; i < b.cases.size() + 2 && ok; i++) {
+      const Case& c = *b.cases[i % b.cases.size()];
+      milzma_output single;
+      memset(&single, 0, sizeof single);
+      const bool batch = i < b.cases.size();
+      if (!batch) milzma_lzma_decompress(ctx, ptr_of(c.data), c.data.size(), &mo, &single);
+      const milzma_output& o = batch ? b.outs[i] : single;
+      orc_result w;
+      memset(&w, 0, sizeof w);
+      orc_lzma_decompress(ptr_of(c.data), c.data.size(), &oo, &w);
+      const bool eof = strstr(w.msg, "failed to fill whole buffer") != nullptr;
+      g_cases++;
+      if (w.kind == ORC_OK || eof) {
+        g_compared++;
+        if (!(o.kind == w.kind && strcmp(o.msg, w.msg) == 0 && o.len == w.out_len && (o.len == 0 || memcmp(o.data, w.out, o.len) == 0) &&
+              o.in_consumed == w.in_consumed)) {
+          printf("MISMATCH %s with options %d (%s): got kind %d '%s' len %zu consumed %zu | oracle kind %d '%s' len %zu consumed %zu\n", c.name.c_str(), v,
+                 batch ? "batch" : "single", o.kind, o.msg, o.len, o.in_consumed, w.kind, w.msg, w.out_len, w.in_consumed);
+          ok = false;
+        }
+      } else {
+        g_skipped++;
+        if (o.kind == MILZMA_OK || o.kind == MILZMA_INFRA_ERROR) {
+          printf("MISMATCH %s with options %d: oracle fails with '%s', the library says kind %d '%s'\n", c.name.c_str(), v, w.msg, o.kind, o.msg);
+          ok = false;
+        }
+      }
+      orc_free(w.out);
+      milzma_free(o.data);
+    }
+  }
   // 5. several devices behind one handle (FAKE_HIP_DEVICES > 1, or MILZMA_MULTI_REPLICAS)
   if (ok) {
     milzma_multi* m = nullptr;
