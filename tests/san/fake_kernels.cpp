@@ -6,11 +6,12 @@
 //     launch is a growing one, and continues -- here: is decoded again into the larger slice -- when an order entry with bit 31 names it;
 //   * streamed launches: every unit's output also goes to its host destination (host_ptrs {address, limit} or host_out + out_off), then
 //     the span counters move; a launch with an in_ready word waits for it before it reads beyond the units' leads (here: before it reads).
-// Only streams the oracle decodes without an error -- and truncated ones (INPUT_EOF) -- get a faithful status; any other failure is reported as
-// MILZMA_ST_L2_INVALID_STATUS / MILZMA_ST_LZ_DIST_DICT with the oracle's bytes: the harness (pipeline_fuzz.cpp) compares what the reference
-// defines for such inputs only where the status is faithful.
+// Every error site of the hot path comes back with the status (and the integers) the real kernels report for it: the oracle's message is
+// parsed back (the inverse of milzma_result_message), so the harness compares EVERY result with the oracle, failed payloads included.
+// (A message that is none of them becomes status 0xFFFF: "unknown status" -- an infrastructure error the harness reports.)
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -88,14 +89,31 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
     visible = size_t(o.out_len < u.out_cap ? o.out_len : u.out_cap);
     r.out_len = r.out_flushed = visible;
     r.in_consumed = o.in_consumed;
-    if (kind == ORC_OK)
-      r.status = MILZMA_ST_OK;
-    else if (strstr(o.msg, "failed to fill whole buffer") && kind == ORC_IO_ERROR)
-      r.status = MILZMA_ST_INPUT_EOF;
-    else if (strstr(o.msg, "too short: failed to fill whole buffer"))   // "LZMA stream too short" / "LZMA input too short": the range coder's first bytes
-      r.status = MILZMA_ST_RC_INIT;
-    else
-      r.status = u.kind == MILZMA_KIND_LZMA2 ? MILZMA_ST_L2_INVALID_STATUS : MILZMA_ST_LZ_DIST_DICT;
+    // the oracle's message back to the status (and the integers) the kernels report for that error site: milzma_result_message's inverse
+    unsigned long long a = 0, b = 0;
+    const char* m = strchr(o.msg, ':');
+    m = m ? m + 2 : o.msg;
+    r.status = 0xFFFFu;
+    if (kind == ORC_OK) r.status = MILZMA_ST_OK;
+    else if (kind == ORC_IO_ERROR && strstr(m, "failed to fill whole buffer")) r.status = MILZMA_ST_INPUT_EOF;
+    else if (strstr(m, "too short: failed to fill whole buffer")) r.status = MILZMA_ST_RC_INIT;
+    else if (sscanf(m, "Match distance %llu is beyond dictionary size %llu", &a, &b) == 2) r.status = MILZMA_ST_MATCH_DIST_DICT;
+    else if (sscanf(m, "Match distance %llu is beyond output size %llu", &a, &b) == 2) r.status = MILZMA_ST_MATCH_DIST_OUT;
+    else if (sscanf(m, "LZ distance %llu is beyond dictionary size %llu", &a, &b) == 2) r.status = MILZMA_ST_LZ_DIST_DICT;
+    else if (sscanf(m, "LZ distance %llu is beyond output size %llu", &a, &b) == 2) r.status = MILZMA_ST_LZ_DIST_OUT;
+    else if (sscanf(m, "exceeded memory limit of %llu", &a) == 1) r.status = MILZMA_ST_MEMLIMIT;
+    else if (strstr(m, "Found end-of-stream marker but more bytes are available")) r.status = MILZMA_ST_MARKER_TRAILING;
+    else if (sscanf(m, "Expected unpacked size of %llu but decompressed to %llu", &a, &b) == 2) r.status = MILZMA_ST_SIZE_MISMATCH;
+    else if (strstr(m, "LZMA2 expected new status")) r.status = MILZMA_ST_L2_STATUS_EOF;
+    else if (sscanf(m, "LZMA2 invalid status %llu", &a) == 1) r.status = MILZMA_ST_L2_INVALID_STATUS;
+    else if (strstr(m, "LZMA2 expected unpacked size")) r.status = MILZMA_ST_L2_UNPACKED_EOF;
+    else if (strstr(m, "LZMA2 expected packed size")) r.status = MILZMA_ST_L2_PACKED_EOF;
+    else if (strstr(m, "LZMA2 expected new properties")) r.status = MILZMA_ST_L2_PROPS_EOF;
+    else if (sscanf(m, "LZMA2 invalid properties: lc + lp (%llu + %llu)", &a, &b) == 2) r.status = MILZMA_ST_L2_LCLP;
+    else if (sscanf(m, "LZMA2 invalid properties: %llu must be", &a) == 1) r.status = MILZMA_ST_L2_PROPS_INVALID;
+    else if (sscanf(m, "LZMA2 expected %llu uncompressed bytes", &a) == 1) r.status = MILZMA_ST_L2_STORED_EOF;
+    r.err_a = a;
+    r.err_b = b;
   }
   if (visible) memcpy(out, o.out, visible);
   if (st && st->progress) {  // the streamed way out: the unit's own destination, then the counters

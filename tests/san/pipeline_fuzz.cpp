@@ -63,9 +63,7 @@ Want oracle_of(const Case& c) {
     orc_lzma2_decompress(p, c.data.size(), &w.r);
   else
     orc_xz_decompress(p, c.data.size(), &w.r);
-  const bool eof = strstr(w.r.msg, "failed to fill whole buffer") != nullptr;
-  const bool payload_msg = strstr(w.r.msg, "LZMA2") || strstr(w.r.msg, "distance") || strstr(w.r.msg, "marker") || strstr(w.r.msg, "Expected unpacked");
-  w.faithful = w.r.kind == ORC_OK || (eof && !strstr(w.r.msg, "LZMA2")) || (c.kind == XZ && !payload_msg && !eof);
+  w.faithful = true;   // (the stand-in kernels report every error site with the real kernels' status: fake_kernels.cpp)
   return w;
 }
 
@@ -623,9 +621,8 @@ int main(int argc, char** argv) {
       orc_result w;
       memset(&w, 0, sizeof w);
       orc_lzma_decompress(ptr_of(c.data), c.data.size(), &oo, &w);
-      const bool eof = strstr(w.msg, "failed to fill whole buffer") != nullptr;
       g_cases++;
-      if (w.kind == ORC_OK || eof) {
+      if (true) {
         g_compared++;
         if (!(o.kind == w.kind && strcmp(o.msg, w.msg) == 0 && o.len == w.out_len && (o.len == 0 || memcmp(o.data, w.out, o.len) == 0) &&
               o.in_consumed == w.in_consumed)) {

@@ -5,7 +5,8 @@ AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer -- witho
 tests/san/fake_hip.cpp is a HIP runtime made of host memory and host threads (a stream = an in-order chain of tasks on threads of their own, so
 work on different streams really overlaps), tests/san/fake_kernels.cpp lets the CPU oracle decode a unit where the kernels would and keeps the
 kernels' contract with the host code (results, parking, span counters, the input-ready word).  tests/san/pipeline_fuzz.cpp drives the public
-entry points over valid and truncated .lzma / LZMA2 / .xz inputs and compares every result with the oracle.  What this checks is the HOST
+entry points over valid, truncated, lying and mutated .lzma / LZMA2 / .xz inputs and compares EVERY result with the oracle (the stand-in kernels
+report each error site with the real kernels' status).  What this checks is the HOST
 logic -- memory safety, data races, and that its many paths all hand the caller the right bytes; parity of the real kernels is `-m gpu`'s business.
 The product library never contains any of this: the fake runtime, the stand-in kernels and the oracle are linked into the test binary only."""
 import lzma
