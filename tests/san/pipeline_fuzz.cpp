@@ -221,12 +221,13 @@ int main(int argc, char** argv) {
   // oracle has it or with an infrastructure error and a text -- never as an empty success, never with a crash, a hang or a leak.
   if (const char* e = getenv("PIPELINE_FAULTS")) {
     const long upto = atol(e);
+    const long stride = getenv("PIPELINE_FAULT_STRIDE") ? std::max(1L, atol(getenv("PIPELINE_FAULT_STRIDE"))) : 1;   // (every k-th call only)
     long worst = 0, infra_files = 0, good_files = 0;
     for (int k = 0; k < 3; k++) {
       Batch b;
       for (uint32_t i = 0; i < 8; i++) b.add(&pool[k][rng.below(uint32_t(pool[k].size()))]);
       long last = upto;   // (after the fault-free run: no further than the calls a batch makes)
-      for (long n = 0; n <= last; n++) {
+      for (long n = 0; n <= last; n += (n == 0 ? 1 : stride)) {
         milzma_ctx* c = nullptr;
         fake_hip_fail_at(n == 0 ? -1 : n);
         if (milzma_create(0, &c) != MILZMA_OK) continue;   // (creation itself failed: reported, nothing to run)
@@ -294,7 +295,7 @@ int main(int argc, char** argv) {
           for (size_t i = 0; i < cs.size(); i++) memcpy(in.data() + units[i].in_off, ptr_of(cs[i]->data), cs[i]->data.size());
         }
         long last = upto;
-        for (long n = 0; n <= last; n++) {
+        for (long n = 0; n <= last; n += (n == 0 ? 1 : stride)) {
           milzma_multi* m = nullptr;
           fake_hip_fail_at(n == 0 ? -1 : n);
           if (milzma_multi_create(0, &m) != MILZMA_OK) continue;
