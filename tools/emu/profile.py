@@ -73,6 +73,42 @@ def sections_table(emu, n, a, executed):
         f.write("\n")
 
 
+# What an instruction costs a wave at four waves per SIMD (cycles), measured: experiments/microbench/order_slots.hip and
+# shadow_slots.hip (profiles/r04_kernel_ab.txt section 3, profiles/r03_shadow_slots_and_spec_walk.txt).  A price list, not a simulator: it
+# ranks the loop's sections by what they cost rather than by how many instructions they issue.
+PRICE = {"v_readlane": 17.3, "valu": 7.0, "salu": 5.0, "cmp_branch": 13.7, "branch": 4.0, "taken": 6.0, "lds": 8.0, "vmem": 8.0, "misc": 2.0}
+
+
+def cost_table(emu, n):
+    """estimated cycles per output byte by section: every executed instruction at the measured price of its kind (a scalar compare whose
+    next instruction is a conditional branch: the pair's price)"""
+    c, tk = emu.counts()
+    text = emu.prog.text
+    tab = {}
+    for i, t in enumerate(text):
+        if not c[i]:
+            continue
+        sec = emu.prog.tag[i][0] or "?"
+        op = t.split()[0]
+        k = asmprog.classify(t)
+        if op.startswith("v_readlane") or op.startswith("v_readfirstlane"):
+            w = PRICE["v_readlane"]
+        elif op.startswith("s_cmp") and i + 1 < len(text) and text[i + 1].split()[0].startswith("s_cbranch"):
+            w = PRICE["cmp_branch"] - PRICE["branch"]
+        elif k == "branch":
+            w = PRICE["branch"]
+        else:
+            w = PRICE.get(k, 5.0)
+        d = tab.setdefault(sec, [0.0, 0.0])
+        d[0] += w * int(c[i]) + PRICE["taken"] * int(tk[i])
+        d[1] += int(c[i])
+    total = sum(v[0] for v in tab.values())
+    print("%-18s %10s %8s %8s" % ("section", "cycles/B", "share", "instr/B"))
+    for sec, v in sorted(tab.items(), key=lambda kv: -kv[1][0]):
+        print("%-18s %10.1f %7.1f%% %8.2f" % (sec, v[0] / n, 100.0 * v[0] / total, v[1] / n))
+    print("%-18s %10.1f" % ("all", total / n))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1 << 20)
@@ -82,6 +118,7 @@ def main():
     ap.add_argument("--index", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="average over this many streams (indices index .. index + streams - 1)")
     ap.add_argument("--sections", default="", help="write the per-section / per-role table (instructions per output byte) to this JSON file and print it")
+    ap.add_argument("--cost", action="store_true", help="estimated cycles per output byte by section, from the measured price of each kind of instruction")
     ap.add_argument("--json", default="", help="also write the mix to this file (bench.py reads profiles/r03_instruction_mix_<config>.json)")
     a = ap.parse_args()
     emu = None
@@ -120,6 +157,8 @@ def main():
             f.write("\n")
     if a.sections:
         sections_table(emu, n, a, executed)
+    if a.cost:
+        cost_table(emu, n)
     if a.regions:
         c, tk = emu.counts()
         reg = {}
