@@ -77,12 +77,36 @@ def effective_cores():
     return max(1, n)
 
 
+def _code_only(text):
+    """C / C++ source without comments and with every run of white space collapsed (string literals kept verbatim)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_hash():
-    """identifies the decode kernel a profile was taken with (profiles/*.json carry the same field)"""
+    """identifies the decode kernel a profile was taken with (profiles/*.json carry the same field): the generated loop and the C++
+    around it WITHOUT comments and layout -- evidence keyed on the bytes of a file kept its stale comments alive"""
     h = hashlib.sha256()
     for name in ("fast_loop_asm.inc", "decode_fast_asm.hip.h"):
-        with open(os.path.join(ROOT, "lzma_rs_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "lzma_rs_amd", "csrc", name), "r") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 
@@ -879,6 +903,14 @@ def main():
     else:
         bad = sum(1 for r in res if r.status != M.ST_OK)
     bad_total = int(D.sum_over_ranks(bad, dev))
+    # who took part: every rank's kernel time, and the physical device behind it -- ranks that share a GPU are a dry run of the rank
+    # logic, never a scaling number (the first contact with an 8-GPU node has to produce the whole curve by itself)
+    table = D.all_ranks([statistics.median(kernel_ms), float(D.device_identity(dev_index))], dev)
+    per_rank_kernel_ms = [round(r[0], 3) for r in table]
+    distinct_devices = len({int(r[1]) for r in table})
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
+    if distinct_devices < world and os.environ.get("MILZMA_DIST_BACKEND") != "gloo":
+        raise SystemExit("bench.py --gpus %d: the %d ranks ran on %d distinct GPU(s); refusing to print a scaling number" % (world, world, distinct_devices))
 
     if scatter:
         D.barrier_sync(dev)
@@ -907,7 +939,8 @@ def main():
                         "scatter_GBps": round(comp_total / max(1, reps) * (world - 1) / max(scatter_s, 1e-9) / 1e9, 2),
                         "gather_GBps": round(out_bytes_rank * (world - 1) / gather_s / 1e9, 2),
                         "gathered_units_bad": gathered_bad,
-                        "note": "rank 0 holds a pool of world x distinct different streams, partitions it by compressed bytes "
+                        "inclusive_GBps": round(out_bytes_rank * world / (scatter_s + elapsed / args.steps + gather_s) / 1e9, 3),
+                        "note": "inclusive_GBps = all ranks' output / (scatter + one decode step + gather); rank 0 holds a pool of world x distinct different streams, partitions it by compressed bytes "
                                 "(milzma_partition) and sends every rank its share; every rank returns its decoded output; "
                                 "point-to-point over the process group (RCCL / xGMI on GPUs); rank 0 CRC-checks every gathered "
                                 "unit on its GPU; not part of `value`"}
@@ -973,6 +1006,10 @@ def main():
             "data": "synthetic",
             "streams_per_s": round(n * world / step_s, 1),
             "bit_exact": bad_total == 0,
+            "ranks": {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": world, "distinct_devices": distinct_devices,
+                      "kernel_ms_per_rank": per_rank_kernel_ms,
+                      "collectives": "rendezvous, barriers, the max-over-ranks step time and this table only: no collective on the decode path"
+                                     + ("" if distinct_devices == world else "; RANKS SHARE A GPU: a dry run of the rank logic, not a scaling number")},
             "config": {
                 "workload": "configs[%d]: %s, lc%d/lp%d/pb%d, dict %d, class %s, liblzma preset 6, known-size headers"
                             % ((cfg["idx"], what) + PROPS + (dict_size, args.kind)),

@@ -153,14 +153,21 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *                         symbol boundary within 273 bytes of the slice's end (nothing of the next symbol looked at), its decoder
  *                         state stays in the context, its result is (MILZMA_ST_OUT_FULL, err_a = MILZMA_PARKED, out_len = bytes
  *                         produced so far, in_consumed = reader position).  A unit whose declared size fits its slice, or whose
- *                         limit is a memlimit, is never parked.  Units the generic kernel decodes (lc + lp > 4) are not parked
- *                         either: they report a plain OUT_FULL (err_a = 0) and must be decoded again from the start.
+ *                         limit is a memlimit, is never parked.  Units of every property set are parked this way since round 4 (lc + lp
+ *                         >= 4 runs in the same kernel with its literal rows in a slab the context keeps beside the parked states;
+ *                         such a unit's result carries bit 0x100 in err_b).  Only units the GENERIC kernel decodes -- the context was
+ *                         created under MILZMA_KERNEL=generic / MILZMA_SPILL=generic, or the slab of a launch could not be
+ *                         allocated -- are not parked: they report a plain OUT_FULL (err_a = 0) and must be decoded again from
+ *                         the start in a larger slice.
  *   MILZMA_DECODE_RESUME  (implies GROW) continues the units the previous _ex call on this context parked: same n, same order;
  *                         `results` holds that call's results on entry, and only entries that say PARKED are touched.  For every
  *                         parked unit the descriptor names the NEW output slice (out_off / out_cap; at least 274 bytes more than
  *                         out_len) whose first out_len bytes hold the output so far -- the unit's dictionary; move them with
  *                         milzma_move_units or keep out_off and raise out_cap when the room behind the slice is free.  No byte is
- *                         decoded twice.  The input (d_in, in_off, in_len) must be what it was.
+ *                         decoded twice.  The input (d_in, in_off, in_len) must be what it was.  The context checks what it can
+ *                         against what it recorded when it parked the units -- a unit that was not parked by the previous call, another
+ *                         in_off / in_len / kind, an out_cap below the out_len it has produced: MILZMA_INFRA_ERROR, nothing launched,
+ *                         the parked states stay -- and takes the launch class from its own record, not from `results`.
  * Parked states live until the next decode call on the context that is not a RESUME. */
 #define MILZMA_DECODE_GROW 1u
 #define MILZMA_DECODE_RESUME 2u

@@ -81,6 +81,19 @@ struct milzma_ctx {
   // call may resume them as long as it is a RESUME with the same n); any other decode call on the context gives the parking lot up
   bool parked_valid = false;
   uint32_t parked_n = 0;
+  // what the GROW / RESUME call that parked them recorded of the parked units (a RESUME is checked against it: the launch class and
+  // the bytes produced so far are the context's knowledge, not the caller's)
+  struct ParkRec {
+    uint64_t in_off = 0, in_len = 0, out_len = 0;
+    uint8_t parked = 0, spill = 0, kind = 0;
+  };
+  std::vector<ParkRec> park_rec;
+  // The literal-row slab of class kFastSpill lives in `scratch`, indexed by unit with ONE stride for the whole batch.  While units of a
+  // GROW batch are (or may still get) parked their trained rows exist only there: slab_live pins the stride (slab_lclp) and the
+  // allocation until the parking lot is given up -- a RESUME launch or a promotion launch sees only a subset of the units and must
+  // neither re-derive the stride from it nor wipe the other units' rows.
+  bool slab_live = false;
+  uint32_t slab_lclp = 0;
   // Streamed launches (the whole-file calls' progressive download): a caller that sets stream_span / stream_spans before the async
   // half asks for the batch's ONE fast launch to run time-sliced with span counters (kernels.h); stream_active says it happened.
   // progress: kMaxSpans counters in mapped host memory, written by the device, polled by SpanPump.
@@ -621,29 +634,47 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
   size_t slab_bytes = 0;
   if (cls == kFastSpill) {
     // The literal rows of every unit of the BATCH in one slab (indexed by unit, like the results: a unit keeps its rows across the
-    // turns of a time-sliced launch and across a park / resume), every probability 0x400 before the first launch.  Not to be had
-    // (half of the free memory at most): the generic kernel's spill class takes the units, chunk by chunk.
-    spill_lclp = 4;   // (at least what an LZMA2 unit can switch to)
-    for (uint32_t i : order) spill_lclp = std::max<uint32_t>(spill_lclp, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
-    spill_lclp = std::min<uint32_t>(spill_lclp, 12);
-    slab_bytes = spill_bytes_per_block(spill_lclp);
-    const size_t total = slab_bytes * ctx->pend_n;
-    size_t free_b = 0, total_b = 0;
-    const bool fits = slab_bytes <= 0xFFFFFFFFu && total <= kSpillSlabBytes * 4 &&
-                      (total <= ctx->scratch.cap || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total <= free_b / 2 + ctx->scratch.cap));
-    const std::string keep = ctx->err;
-    if (!fits || !dev_reserve(ctx, ctx->scratch, total)) {
-      ctx->err = keep;
-      if (resume) {
-        ctx->err = "no memory for the literal-row slab of parked units";
+    // turns of a time-sliced launch and across a park / resume), every probability of THIS launch's units 0x400 before it starts.  Not
+    // to be had (half of the free memory at most): the generic kernel's spill class takes the units, chunk by chunk.
+    uint32_t need = 4;   // (at least what an LZMA2 unit can switch to)
+    for (uint32_t i : order) need = std::max<uint32_t>(need, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
+    need = std::min<uint32_t>(need, 12);
+    if (ctx->slab_live) {
+      // units of this batch are parked (or may be, by an earlier launch of this very call) with their rows in the slab: the stride and the
+      // allocation are the ones the batch's first launch of this class chose -- never derived from the subset this launch sees
+      spill_lclp = ctx->slab_lclp;
+      slab_bytes = spill_bytes_per_block(spill_lclp);
+      if (need > spill_lclp || slab_bytes * ctx->pend_n > ctx->scratch.cap) {
+        ctx->err = "the literal-row slab of the parked units does not fit this launch";
         return false;
       }
-      return launch_class(ctx, kLitSpill, order, order_base, d_in, d_out, stream);
+    } else {
+      spill_lclp = need;
+      slab_bytes = spill_bytes_per_block(spill_lclp);
+      const size_t total = slab_bytes * ctx->pend_n;
+      size_t free_b = 0, total_b = 0;
+      const bool fits = slab_bytes <= 0xFFFFFFFFu && total <= kSpillSlabBytes * 4 &&
+                        (total <= ctx->scratch.cap || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total <= free_b / 2 + ctx->scratch.cap));
+      const std::string keep = ctx->err;
+      if (resume || !fits || !dev_reserve(ctx, ctx->scratch, total)) {
+        ctx->err = keep;
+        if (resume) {   // (units parked in this class without a live slab: the context was used for something else in between)
+          ctx->err = "no literal-row slab for the parked units";
+          return false;
+        }
+        return launch_class(ctx, kLitSpill, order, order_base, d_in, d_out, stream);
+      }
+      ctx->slab_lclp = spill_lclp;
+      ctx->slab_live = grow;   // (only a growing batch parks units beyond its launches)
     }
-    if (!resume && !hip_ok(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(ctx->scratch.p), 0x0400, total / 2, stream), "slab memset"))
+    if (!resume && !hip_ok(ctx, launch_slab_init(static_cast<uint8_t*>(ctx->scratch.p), uint32_t(slab_bytes), d_order, n, stream), "slab init"))
       return false;
   }
   if (cls == kLitSpill) {
+    if (ctx->slab_live) {   // (its table would go where the parked units' rows are)
+      ctx->err = "the generic spill class cannot run while parked units keep their literal rows in the scratch slab";
+      return false;
+    }
     for (uint32_t i : order) spill_lclp = std::max<uint32_t>(spill_lclp, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
     spill_lclp = std::min<uint32_t>(spill_lclp, 12);
     size_t free_b = 0, total_b = 0;
@@ -756,7 +787,10 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
     ctx->err = "MILZMA_DECODE_RESUME: this context holds no parked units of a batch of that size";
     return MILZMA_INFRA_ERROR;
   }
-  if (!resume) ctx->parked_valid = false;  // (whatever was parked here is given up: the parking lot serves this batch now)
+  if (!resume) {  // (whatever was parked here is given up: the parking lot and the slab serve this batch now)
+    ctx->parked_valid = false;
+    ctx->slab_live = false;
+  }
   if (ctx->pending) {
     ctx->err = "a batch is already in flight on this context: call milzma_decode_units_wait first";
     return MILZMA_INFRA_ERROR;
@@ -779,6 +813,10 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   // result buffer and the device buffers, so the stream is drained before the batch is declared gone.
   const auto fail = [&]() {
     const std::string why = ctx->err;
+    // (a streamed launch already enqueued may have persistent waves spinning on the input-ready word, which only the second upload would
+    //  set -- and this call is not going to get there: released first, or the drain below never returns.  What those waves decode is
+    //  thrown away with the call.)
+    if (ctx->stream_in_host && ctx->progress) __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 1u, __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(stream);
     ctx->err = why;
     ctx->ev_used = 0;
@@ -802,10 +840,21 @@ static int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* un
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
   std::vector<uint32_t> order[kNumLitClasses];
-  if (resume) {  // only what the previous call parked, each unit in the class it was parked in (err_b: the instantiation's rows)
+  if (resume) {  // only what the previous call parked, each unit in the class the CONTEXT knows it was parked in
     for (uint32_t i = 0; i < n; i++)
-      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED)
-        order[(prev[i].err_b & 0x100) ? kFastSpill : kFast].push_back(i);
+      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED) {
+        const milzma_ctx::ParkRec* rec = i < ctx->park_rec.size() ? &ctx->park_rec[i] : nullptr;
+        const char* why = !rec || !rec->parked                                                        ? "was not parked by the previous call"
+                          : units[i].in_off != rec->in_off || units[i].in_len != rec->in_len || units[i].kind != rec->kind ? "names another input than the one it was parked with"
+                          : units[i].out_cap < rec->out_len                                           ? "has a slice smaller than the output it has produced"
+                                                                                                      : nullptr;
+        if (why) {  // (nothing is launched: a descriptor that does not fit the parked state would write outside its slice)
+          ctx->err = "MILZMA_DECODE_RESUME: unit " + std::to_string(i) + " " + why;
+          ctx->pending = false;
+          return MILZMA_INFRA_ERROR;
+        }
+        order[rec->spill ? kFastSpill : kFast].push_back(i);
+      }
   } else {
     for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
   }
@@ -937,6 +986,18 @@ static int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results
     for (uint32_t i = 0; i < n && !any; i++) any = results[i].status == MILZMA_ST_OUT_FULL && results[i].err_a == MILZMA_PARKED;
     ctx->parked_valid = any;
     ctx->parked_n = n;
+    if (!any) ctx->slab_live = false;
+    ctx->park_rec.assign(any ? n : 0, milzma_ctx::ParkRec());
+    for (uint32_t i = 0; any && i < n; i++)
+      if (results[i].status == MILZMA_ST_OUT_FULL && results[i].err_a == MILZMA_PARKED) {
+        milzma_ctx::ParkRec& r = ctx->park_rec[i];
+        r.parked = 1;
+        r.spill = (results[i].err_b & 0x100) ? 1 : 0;
+        r.kind = uint8_t(ctx->pend_units[i].kind);
+        r.in_off = ctx->pend_units[i].in_off;
+        r.in_len = ctx->pend_units[i].in_len;
+        r.out_len = results[i].out_len;
+      }
   }
   return MILZMA_OK;
 }
@@ -2892,6 +2953,7 @@ static inline void begin_call(milzma_ctx* ctx) {
 static int unit_call_threw(milzma_ctx* ctx, const std::exception& e) {
   if (ctx) {
     if (ctx->pending) {
+      if (ctx->progress) __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 1u, __ATOMIC_RELEASE);  // (waves waiting for a second upload: see fail())
       (void)hipSetDevice(ctx->device);
       (void)hipDeviceSynchronize();
     }

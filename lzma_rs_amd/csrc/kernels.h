@@ -54,6 +54,10 @@ uint32_t stream_lead_bytes(uint32_t in_len);
 // grow: growable output (milzma_decode_units_ex) -- a unit that runs out of room is parked in d_ctxmem with status OUT_FULL /
 // err_a = MILZMA_PARKED; d_order entries with bit 31 set resume such a unit (parked by an earlier launch with the same d_ctxmem)
 
+// every probability (u16) of the literal-row slabs of the units d_order[0 .. n) = 0x400: d_slab + unit * slab_bytes, slab_bytes each.  Only
+// THOSE units' rows: other units of the batch may be parked with their trained rows in the same slab (bit 31 of an entry is ignored).
+hipError_t launch_slab_init(uint8_t* d_slab, uint32_t slab_bytes, const uint32_t* d_order, uint32_t n, hipStream_t stream);
+
 // d_offs: 3 n device words -- src_off[n], dst_off[n], len[n]
 hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream);
 

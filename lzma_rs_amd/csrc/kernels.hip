@@ -143,6 +143,30 @@ hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_
   return hipGetLastError();
 }
 
+// One block per (unit, 16 KiB piece) of the units' literal-row slabs (1536 B << lc+lp each: a multiple of 16 KiB from lc + lp = 4 on... of 8 KiB
+// at 4: the tail piece is short): 16-byte stores of 0x0400 0x0400 ...
+__global__ __launch_bounds__(256) void slab_init_kernel(uint8_t* __restrict__ slab, uint32_t slab_bytes, const uint32_t* __restrict__ order, uint32_t n) {
+  const uint32_t k = blockIdx.x;
+  if (k >= n) return;
+  const uint32_t unit = order[k] & 0x7FFFFFFFu;
+  const size_t lo = size_t(blockIdx.y) * 16384u;
+  if (lo >= slab_bytes) return;
+  const size_t hi = lo + 16384u < slab_bytes ? lo + 16384u : size_t(slab_bytes);
+  uint4* p = reinterpret_cast<uint4*>(slab + size_t(unit) * slab_bytes + lo);
+  const uint4 v = make_uint4(0x04000400u, 0x04000400u, 0x04000400u, 0x04000400u);
+  for (size_t i = threadIdx.x; i < (hi - lo) / 16; i += blockDim.x) p[i] = v;
+}
+
+hipError_t launch_slab_init(uint8_t* d_slab, uint32_t slab_bytes, const uint32_t* d_order, uint32_t n, hipStream_t stream) {
+  if (n == 0 || slab_bytes == 0) return hipSuccess;
+  const uint32_t pieces = uint32_t((size_t(slab_bytes) + 16383u) / 16384u);   // (<= 384 at lc + lp = 12)
+  for (uint32_t i = 0; i < n; i += 65535u * 32u) {                            // (grid.x limit: 2^31 - 1; kept far below it)
+    const uint32_t m = std::min<uint32_t>(n - i, 65535u * 32u);
+    hipLaunchKernelGGL(slab_init_kernel, dim3(m, pieces), dim3(256), 0, stream, d_slab, slab_bytes, d_order + i, m);
+  }
+  return hipGetLastError();
+}
+
 uint32_t stream_lead_bytes(uint32_t in_len) { return stream_lead(in_len); }
 
 hipError_t launch_crc_units(const milzma_unit* d_units, uint32_t n, const uint8_t* d_out, const milzma_result* d_results,

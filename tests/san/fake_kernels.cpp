@@ -4,6 +4,10 @@
 //   * one milzma_result per unit (status, out_len, out_flushed, in_consumed), written when the launch's task runs on its stream;
 //   * growable output: a unit that does not fit its slice is parked (OUT_FULL, err_a = MILZMA_PARKED, out_len = what is in the slice) if the
 //     launch is a growing one, and continues -- here: is decoded again into the larger slice -- when an order entry with bit 31 names it;
+//   * the literal-row slab of class kFastSpill (round 5): a launch's units find their rows initialised (every probability 0x400: launch_slab_init) at
+//     d_slab + unit * slab_bytes, a unit that parks leaves its trained rows there (here: a signature naming the unit and the stride), and a resumed
+//     unit must find them where it left them -- a host that re-derives the stride from the resumed subset, or wipes the slab for another launch of
+//     the batch, is caught (status 0xFFFF: the harness reports it);
 //   * streamed launches: every unit's output also goes to its host destination (host_ptrs {address, limit} or host_out + out_off), then
 //     the span counters move; a launch with an in_ready word waits for it before it reads beyond the units' leads (here: before it reads).
 // Every error site of the hot path comes back with the status (and the integers) the real kernels report for it: the oracle's message is
@@ -56,10 +60,25 @@ uint32_t first_lclp(const uint8_t* in, size_t n) {
   return 0;
 }
 
+constexpr uint64_t kRowsMagic = 0x524f57535f4f4b21ull;   // what a parked unit's rows look like in the slab: {magic, unit, stride}
+
 void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_t* d_out, milzma_result* res, bool grow, const Streamed* st,
-                bool has_slab) {
+                const uint8_t* d_slab, uint32_t slab_bytes, bool resume) {
+  const bool has_slab = d_slab != nullptr;
   milzma_result r;
   memset(&r, 0, sizeof r);
+  uint64_t* rows = has_slab && slab_bytes >= 64 ? reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(d_slab) + size_t(uidx) * slab_bytes) : nullptr;
+  if (rows) {  // the rows must be what the kernel's contract says: fresh for a first launch, this unit's own for a resumed one
+    const uint64_t fresh = 0x0400040004000400ull;
+    const bool ok = resume ? rows[0] == kRowsMagic && rows[1] == uidx && rows[2] == slab_bytes && rows[slab_bytes / 8 - 1] == kRowsMagic
+                           : rows[0] == fresh && rows[1] == fresh && rows[2] == fresh && rows[slab_bytes / 8 - 1] == fresh;
+    if (!ok) {
+      fprintf(stderr, "fake kernel: unit %u finds %s literal rows in the slab (stride %u)\n", uidx, resume ? "someone else's / wiped" : "uninitialised", slab_bytes);
+      r.status = 0xFFFFu;
+      res[uidx] = r;
+      return;
+    }
+  }
   orc_result o;
   memset(&o, 0, sizeof o);
   const uint8_t* in = d_in + u.in_off;
@@ -82,6 +101,13 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
   if (kind == ORC_OK && o.out_len > u.out_cap) {  // does not fit: parked in front of the symbol that would not (here: a little before the end)
     r.status = MILZMA_ST_OUT_FULL;
     r.err_a = grow ? MILZMA_PARKED : 0;
+    r.err_b = grow && has_slab ? 0x100u : 0u;   // (the launch class it resumes in, as the real kernel reports it)
+    if (grow && rows) {
+      rows[0] = kRowsMagic;
+      rows[1] = uidx;
+      rows[2] = slab_bytes;
+      rows[slab_bytes / 8 - 1] = kRowsMagic;
+    }
     visible = size_t(u.out_cap > 300 ? u.out_cap - 300 : 0);
     r.out_len = r.out_flushed = visible;
     r.in_consumed = 0;
@@ -132,7 +158,7 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
 }
 
 void run_units(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
-               bool grow, Streamed st, bool has_slab) {
+               bool grow, Streamed st, const uint8_t* d_slab, uint32_t slab_bytes = 0) {
   if (st.in_ready)
     while (__atomic_load_n(st.in_ready, __ATOMIC_ACQUIRE) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
   // a few host threads stand for the chip: units really finish in any order and at the same time
@@ -141,7 +167,7 @@ void run_units(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, 
   const auto body = [&](unsigned k) {
     for (uint32_t i = k; i < n; i += t) {
       const uint32_t uidx = d_order[i] & 0x7FFFFFFFu;
-      decode_one(d_units[uidx], uidx, d_in, d_out, d_results, grow, st.progress ? &st : nullptr, has_slab);
+      decode_one(d_units[uidx], uidx, d_in, d_out, d_results, grow, st.progress ? &st : nullptr, d_slab, slab_bytes, (d_order[i] & 0x80000000u) != 0);
     }
   };
   for (unsigned k = 1; k < t; k++) th.emplace_back(body, k);
@@ -156,14 +182,14 @@ namespace milzma {
 hipError_t launch_generic(LitClass, const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                           milzma_result* d_results, uint16_t*, uint32_t, hipStream_t stream) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
-  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), true); });
+  static const uint8_t generic_has_its_own_tables = 0;   // (any lc + lp: never sent back for another class)
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), &generic_has_its_own_tables); });
   return hipSuccess;
 }
 hipError_t launch_fast(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
-                       hipStream_t stream, uint32_t, uint32_t*, const uint8_t* d_slab, uint32_t) {
+                       hipStream_t stream, uint32_t, uint32_t*, const uint8_t* d_slab, uint32_t slab_bytes) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
-  const bool has_slab = d_slab != nullptr;
-  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), has_slab); });
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, false, Streamed(), d_slab, slab_bytes); });
   return hipSuccess;
 }
 uint32_t fast_resident_blocks(uint32_t) { return 16; }   // (a small chip: launches of more units than that take the time-sliced form)
@@ -172,7 +198,7 @@ size_t slice_queue_bytes(uint32_t cap) { return size_t(cap) * 8 + 64; }
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool grow,
                               uint32_t span_bytes, uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready,
-                              const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t) {
+                              const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t slab_bytes) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
   Streamed st;
   st.span = span_bytes;
@@ -181,13 +207,22 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
   st.host_out = host_out;
   st.in_ready = in_ready;
   st.host_ptrs = host_ptrs;
-  const bool has_slab = d_slab != nullptr;
-  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, grow, st, has_slab); });
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, grow, st, d_slab, slab_bytes); });
   return hipSuccess;
 }
 uint32_t stream_lead_bytes(uint32_t in_len) {
   const uint32_t q4 = in_len >> 2;
   return q4 > 4096u ? q4 : 4096u;   // (the real kernels: a quarter, at least 128 KiB -- small here, so that small files have a second part)
+}
+hipError_t launch_slab_init(uint8_t* d_slab, uint32_t slab_bytes, const uint32_t* d_order, uint32_t n, hipStream_t stream) {
+  if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
+  fake_hip_enqueue(stream, [=] {
+    for (uint32_t i = 0; i < n; i++) {
+      uint16_t* p = reinterpret_cast<uint16_t*>(d_slab + size_t(d_order[i] & 0x7FFFFFFFu) * slab_bytes);
+      for (uint32_t k = 0; k < slab_bytes / 2; k++) p[k] = 0x0400;
+    }
+  });
+  return hipSuccess;
 }
 hipError_t launch_move_units(const uint8_t* d_src, uint8_t* d_dst, const uint64_t* d_offs, uint32_t n, hipStream_t stream) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;

@@ -138,6 +138,147 @@ bool run_batch(milzma_ctx* ctx, Kind kind, Batch& b, const char* via) {
   return b.verify(via);
 }
 
+
+// 3c (round 5).  RAW .lzma units of MIXED literal-row classes (lc + lp <= 3: no slab; 4 .. 12: rows in the slab, one stride per batch) through a
+// caller's own GROW / move / RESUME loop from tiny slices, the known-size ones in slices that fit (they finish in the first call while the
+// others park): the resumed subset then no longer holds the unit with the largest lc + lp, and the stride, the allocation and the other
+// units' rows must stay what the first launch made them (the stride used to be re-derived from the resumed subset; a promotion
+// launch used to wipe the whole slab).  One LZMA2 unit whose first chunk asks for lc + lp = 4 rides along: it is promoted into the slab's
+// class by a launch of its own in the middle of the batch.  Also: a RESUME whose descriptors do not fit the parked states is refused.
+bool raw_grow_loop(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, const std::vector<Case>& lzma2_pool) {
+  struct Item {
+    const Case* c;
+    milzma_unit u;
+    size_t hdr;
+    orc_result want;
+  };
+  std::vector<Item> items;
+  bool have_big = false, have_small_unknown = false;
+  for (const Case& c : lzma_pool) {
+    if (items.size() >= 48) break;
+    Item it;
+    it.c = &c;
+    memset(&it.u, 0, sizeof it.u);
+    memset(&it.want, 0, sizeof it.want);
+    size_t hl = 0;
+    milzma_output ho;
+    memset(&ho, 0, sizeof ho);
+    if (milzma_lzma_read_header(ptr_of(c.data), c.data.size(), nullptr, &it.u, &hl, &ho) != MILZMA_OK) continue;
+    orc_lzma_decompress(ptr_of(c.data), c.data.size(), nullptr, &it.want);
+    if (it.want.kind != ORC_OK || it.want.out_len < 2000) {
+      orc_free(it.want.out);
+      continue;
+    }
+    it.hdr = hl;
+    const uint32_t lclp = uint32_t(it.u.lc) + it.u.lp;
+    have_big = have_big || lclp > 4;
+    have_small_unknown = have_small_unknown || (lclp == 4 && it.u.unpacked_size == MILZMA_SIZE_UNKNOWN);
+    items.push_back(it);
+  }
+  for (const Case& c : lzma2_pool) {   // one LZMA2 unit that will be promoted (lc + lp = 4 in its first chunk) and is long enough to park
+    Item it;
+    it.c = &c;
+    memset(&it.u, 0, sizeof it.u);
+    memset(&it.want, 0, sizeof it.want);
+    if (c.name.find("22.lzma2") == std::string::npos || c.name.find('(') != std::string::npos) continue;
+    orc_lzma2_decompress(ptr_of(c.data), c.data.size(), &it.want);
+    if (it.want.kind != ORC_OK || it.want.out_len < 2000) {
+      orc_free(it.want.out);
+      continue;
+    }
+    it.u.kind = MILZMA_KIND_LZMA2;
+    it.hdr = 0;
+    items.push_back(it);
+    break;
+  }
+  bool ok = true;
+  if (!items.empty()) {
+    const uint32_t n = uint32_t(items.size());
+    std::vector<milzma_unit> units(n);
+    size_t io = 0, oo = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      milzma_unit& u = items[i].u;
+      u.in_off = io;
+      u.in_len = items[i].c->data.size() - items[i].hdr;
+      io += (size_t(u.in_len) + 255) & ~size_t(255);
+      // the units with the most literal rows get room at once (they finish in the first call), everything else starts far too small
+      const bool roomy = u.kind == MILZMA_KIND_RAW_LZMA && uint32_t(u.lc) + u.lp > 4;
+      u.out_off = oo;
+      u.out_cap = roomy ? items[i].want.out_len + 300 : 700;
+      oo += (size_t(u.out_cap) + 255) & ~size_t(255);
+      units[i] = u;
+    }
+    std::vector<uint8_t> in(io + 512, 0), out(oo + 512, 0);
+    for (uint32_t i = 0; i < n; i++) memcpy(in.data() + units[i].in_off, ptr_of(items[i].c->data) + items[i].hdr, size_t(units[i].in_len));
+    std::vector<milzma_result> res(n);
+    uint32_t flags = MILZMA_DECODE_GROW;
+    int rounds_done = 0;
+    bool refused_checked = false;
+    for (;; rounds_done++) {
+      if (milzma_decode_units_ex(ctx, units.data(), n, in.data(), out.data(), res.data(), nullptr, flags) != MILZMA_OK) {
+        printf("INFRA raw grow loop, round %d: %s\n", rounds_done, milzma_last_error(ctx));
+        ok = false;
+        break;
+      }
+      std::vector<uint64_t> so, dof, ln;
+      std::vector<milzma_unit> next = units;
+      size_t total = 0;
+      bool any = false;
+      for (uint32_t i = 0; i < n; i++) {
+        const bool parked = res[i].status == MILZMA_ST_OUT_FULL && res[i].err_a == MILZMA_PARKED;
+        any = any || parked;
+        next[i].out_off = total;
+        next[i].out_cap = parked ? units[i].out_cap * 4 : units[i].out_cap;
+        so.push_back(units[i].out_off);
+        dof.push_back(total);
+        ln.push_back(res[i].out_len < units[i].out_cap ? res[i].out_len : units[i].out_cap);
+        total += (size_t(next[i].out_cap) + 255) & ~size_t(255);
+      }
+      if (!any) break;
+      if (!refused_checked) {   // a RESUME that names a slice smaller than what a parked unit has produced is refused, nothing launched
+        refused_checked = true;
+        std::vector<milzma_unit> bad = units;
+        std::vector<milzma_result> r2 = res;
+        for (uint32_t i = 0; i < n; i++)
+          if (res[i].status == MILZMA_ST_OUT_FULL && res[i].err_a == MILZMA_PARKED && res[i].out_len > 16) {
+            bad[i].out_cap = res[i].out_len - 16;
+            break;
+          }
+        if (milzma_decode_units_ex(ctx, bad.data(), n, in.data(), out.data(), r2.data(), nullptr, MILZMA_DECODE_RESUME) != MILZMA_INFRA_ERROR) {
+          printf("MISMATCH a RESUME with a slice below the parked unit's output was not refused\n");
+          ok = false;
+          break;
+        }
+      }
+      std::vector<uint8_t> bigger(total + 512, 0);
+      if (milzma_move_units(ctx, n, out.data(), so.data(), bigger.data(), dof.data(), ln.data(), nullptr) != MILZMA_OK) {
+        printf("INFRA move_units (raw grow loop): %s\n", milzma_last_error(ctx));
+        ok = false;
+        break;
+      }
+      out.swap(bigger);
+      units = next;
+      flags = MILZMA_DECODE_RESUME;
+    }
+    for (uint32_t i = 0; i < n && ok; i++) {
+      g_cases++;
+      g_compared++;
+      const orc_result& w = items[i].want;
+      if (res[i].status != MILZMA_ST_OK || res[i].out_len != w.out_len || memcmp(out.data() + units[i].out_off, w.out, w.out_len) != 0) {
+        printf("MISMATCH raw unit %u (%s, lc %u lp %u) after %d grow rounds: status %u len %" PRIu64 " (want %zu)\n", i, items[i].c->name.c_str(),
+               items[i].u.lc, items[i].u.lp, rounds_done, res[i].status, res[i].out_len, w.out_len);
+        ok = false;
+      }
+    }
+    if (ok && have_big && have_small_unknown && rounds_done < 2) {
+      printf("MISMATCH the raw grow loop never resumed anything (%d rounds)\n", rounds_done);
+      ok = false;
+    }
+  }
+  for (Item& it : items) orc_free(it.want.out);
+  return ok;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -504,6 +645,7 @@ int main(int argc, char** argv) {
         }
     }
     for (auto& w : want) orc_free(w.out);
+    if (ok) ok = raw_grow_loop(ctx, pool[LZMA], pool[LZMA2]);
     // milzma_xz_plan: the Index of a good file -> one unit per block; decoded, every block's bytes where the plan put them
     for (const Case& c : pool[XZ]) {
       if (!ok) break;

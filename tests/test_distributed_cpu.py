@@ -73,8 +73,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_gloo(world):
+    """world 2 and 3 (unequal chunk / output sizes per rank; rank 0 posts every receive of the gather before it waits for any)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -86,7 +87,7 @@ def test_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, t, total, n, ok in res:
-        assert t == 2.0 and total == 30.0 and n == 100 + 50 * rank and ok
+        assert t == float(world) and total == 10.0 * world * (world + 1) / 2 and n == 100 + 50 * rank and ok
 
 
 def test_bench_rank_logic_two_ranks_gloo():

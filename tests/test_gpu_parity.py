@@ -994,6 +994,92 @@ def test_growable_units_park_and_resume(ctx):
         assert ever >= n // 2 and rounds >= 3, (ever, rounds)
 
 
+def _rows_stream(lc, lp, pb, size, seed, known):
+    """a .lzma stream of a property set liblzma cannot write (greedy LZ parse + the tests' symbol encoder)"""
+    plain = W.make_plain("text", size - 2048, seed=seed) + bytes(range(256)) * 8
+    enc = E.LzmaSymbolEncoder(lc, lp, pb)
+    enc.encode(E.lz_parse(plain, dict_size=1 << 16))
+    if not known:
+        enc.encode([("marker",)])
+    return E.lzma_header(lc, lp, pb, 1 << 16, len(plain) if known else None) + enc.finish()
+
+
+def test_grow_batch_of_mixed_literal_row_classes(ctx):
+    """ADVICE r4 (two high findings): the literal rows of lc + lp >= 4 units live in ONE slab per batch, indexed by unit with one stride.
+    A GROW batch in which the units with the MOST rows (lc 8, known size, roomy slices) finish at once while units with fewer rows (lc + lp
+    4 .. 6, unknown size, tiny slices) park: the RESUME launches see only the parked subset -- the stride must stay the one the first
+    launch chose (it used to be re-derived: rows read out of another unit's) --, and an LZMA2 unit whose chunk asks for lc + lp = 4 is
+    promoted into the slab's class by a launch of its own in the middle (it used to wipe the whole slab: parked units resumed on fresh
+    probabilities).  Bytes, verdicts and reader positions are the oracle's; then the same files through the whole-file batch call."""
+    import torch
+    specs = [((8, 0, 2), True), ((4, 0, 2), False), ((8, 0, 0), True), ((1, 3, 0), False), ((6, 0, 2), False), ((5, 2, 4), False),
+             ((3, 0, 2), False), ((8, 4, 4), True), ((4, 0, 4), False), ((0, 4, 1), False)]
+    comps, refs, kinds = [], [], []
+    for k, ((lc, lp, pb), known) in enumerate(specs):
+        c = _rows_stream(lc, lp, pb, 60000 + 3000 * k, 1200 + k, known)
+        if k == 5:
+            c = c[:len(c) * 3 // 4]                      # a truncated one: the oracle's error, wherever it was parked before
+        comps.append(c)
+        refs.append(orc.lzma_decompress(c))
+        kinds.append(M.KIND_RAW_LZMA)
+    flt = [{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16, "lc": 2, "lp": 2, "pb": 2}]
+    l2 = lzma.compress(W.make_plain("text", 90000, seed=77), format=lzma.FORMAT_RAW, filters=flt)
+    comps.append(l2)
+    refs.append(orc.lzma2_decompress(l2))
+    kinds.append(M.KIND_LZMA2)
+    n = len(comps)
+    units = (M.Unit * n)()
+    in_off, blobs, total = 0, [], 0
+    for i, c in enumerate(comps):
+        if kinds[i] == M.KIND_RAW_LZMA:
+            u, hl = M.lzma_read_header(c)
+        else:
+            u, hl = M.Unit(), 0
+            u.kind = M.KIND_LZMA2
+        payload = c[hl:]
+        u.in_off, u.in_len = in_off, len(payload)
+        known = kinds[i] == M.KIND_RAW_LZMA and specs[i][1]
+        u.out_cap = len(refs[i].out) + 64 if known else [400, 1500, 5000][i % 3]
+        u.out_off = total
+        total += (u.out_cap + 255) & ~255
+        units[i] = u
+        pad = (-len(payload)) % 256
+        blobs.append(payload + bytes(pad))
+        in_off += len(payload) + pad
+    d_in = torch.frombuffer(bytearray(b"".join(blobs) + bytes(512)), dtype=torch.uint8).cuda()
+    make = lambda nbytes: torch.zeros(nbytes + 512, dtype=torch.uint8, device="cuda")
+    res, d_out, rounds, ever = _resume_until_done(ctx, units, d_in, make, make(total))
+    host = d_out.cpu().numpy().tobytes()
+    fast = os.environ.get("MILZMA_KERNEL") != "generic"
+    for i in range(n):
+        ref, r = refs[i], res[i]
+        kind, msg = M.result_message(r, kinds[i])
+        if r.status == M.ST_OUT_FULL:       # only the generic kernel's units may end like this (they cannot be parked)
+            assert not fast and r.err_a == 0, (i, r.status, r.err_a)
+            continue
+        assert (kind, msg) == (ref.kind, ref.msg), (i, msg, ref.msg)
+        got = host[units[i].out_off:units[i].out_off + min(r.out_flushed, units[i].out_cap)]
+        assert got == ref.out, (i, len(got), len(ref.out))
+        if ref.ok:
+            assert r.in_consumed + (13 if kinds[i] == M.KIND_RAW_LZMA else 0) == ref.in_consumed, i
+    if fast:
+        assert ever >= 6 and rounds >= 3, (ever, rounds)
+        # a RESUME whose descriptor does not fit the parked state is refused (nothing launched): park once more, then lie about a slice
+        for i in range(n - 1):
+            if not specs[i][1]:
+                units[i].out_cap = 300
+        res2, _, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_GROW)
+        parked = [i for i in range(n) if res2[i].status == M.ST_OUT_FULL and res2[i].err_a == M.PARKED]
+        assert parked
+        units[parked[0]].out_cap = max(1, res2[parked[0]].out_len - 8)
+        with pytest.raises(M.InfraError):
+            ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_RESUME, results=res2)
+    # the whole-file call: unknown-size members get a guessed slice and are grown (park / move / resume inside the library)
+    many = [comps[i % (n - 1)] for i in range(3 * (n - 1))]
+    for i, d in enumerate(ctx.lzma_batch(many)):
+        same(d, refs[i % (n - 1)])
+
+
 def test_thousands_of_wrong_guesses_are_resumed_not_redecoded(ctx):
     """4200 marker-terminated streams whose output is a thousand times their input (zeros / repeats: the whole-file path's first
     slice, 6 x the payload or 64 KiB, is wrong for every one of them) next to text streams whose guess holds: the batch call parks

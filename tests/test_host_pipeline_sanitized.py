@@ -45,6 +45,16 @@ def inputs(tmp_path_factory):
                 (d / ("%s_%d_%d_%s.xz" % (kind, size, bs, chk))).write_bytes(W.compress_xz_blocks(plain, block_size=bs, check=chk))
             flt = [{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16, "lc": 1, "lp": 3, "pb": 0}]
             (d / ("%s_%d_lclp4.xz" % (kind, size))).write_bytes(lzma.compress(plain, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64, filters=flt))
+    # literal-row classes liblzma cannot write (lc + lp > 4: symbol encoder of the tests) next to lc + lp = 4 streams of unknown size: in one
+    # GROW batch the former finish while the latter park, and the slab's stride must outlive the launch that chose it (pipeline_fuzz: 3c)
+    import lzma_enc as E
+    for (lc, lp, pb), known in (((8, 0, 2), True), ((5, 2, 4), True), ((6, 0, 0), False), ((4, 0, 2), False), ((1, 3, 0), False)):
+        plain = W.make_plain("text", 24000, seed=700 + lc * 10 + lp) + bytes(range(256)) * 8
+        enc = E.LzmaSymbolEncoder(lc, lp, pb)
+        enc.encode(E.lz_parse(plain, dict_size=1 << 16))
+        if not known:
+            enc.encode([("marker",)])
+        (d / ("rows_%d%d%d_%d.lzma" % (lc, lp, pb, known))).write_bytes(E.lzma_header(lc, lp, pb, 1 << 16, len(plain) if known else None) + enc.finish())
     # .xz files whose Index lies about a block's size (by a little: the block still fits its slice but not its place; by a lot: its unit
     # runs out of room and the block is decoded on demand -- then COPIED into a buffer whose later places already hold the next blocks:
     # round 4's GPU fuzz found that copy running over them; ASan's memcpy-param-overlap finds it here)

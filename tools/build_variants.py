@@ -37,6 +37,12 @@ def main():
                         k, v = item.split("=", 1)
                         env[k if k.startswith("MILZMA_GEN_") else "MILZMA_GEN_" + k] = v
             gen(env)
+            # the hazards inline asm must respect itself (v_readlane after a VALU write, VALU reads of fresh lane masks): linted per variant
+            lint = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(ROOT, "tests", "test_host_abi.py") + "::test_asm_loop_wait_states"],
+                                  capture_output=True, text=True, cwd=ROOT)
+            if lint.returncode != 0:
+                sys.stderr.write(lint.stdout[-1500:])
+                raise SystemExit("variant %s fails the wait-state lint" % name)
             out = os.path.join("..", "variants", "libmilzma_%s.so" % name)
             r = subprocess.run(["make", "-C", CSRC, "-s", "-B", "CXXFLAGS=" + " ".join([BASE_FLAGS] + flags), "OUT=" + out],
                                capture_output=True, text=True)

@@ -109,6 +109,69 @@ def cost_table(emu, n):
     print("%-18s %10.1f" % ("all", total / n))
 
 
+def form_of(text):
+    """opcode + the operand kinds that decide which issue class a vector instruction falls in: s = a scalar register among its sources,
+    l = a 32-bit literal (an integer outside the inline range -16 .. 64)"""
+    import re
+    t = text.replace(",", " ").split()
+    op, ops = t[0], t[1:]
+    if not op.startswith("v_"):
+        return op
+    flags = ""
+    srcs = ops[1:]
+    if any(re.match(r"^(s\d+|s\[\d+:\d+\]|vcc|m0|exec)$", o) for o in srcs):
+        flags += "s"
+    for o in srcs:
+        try:
+            v = int(o, 0)
+        except ValueError:
+            continue
+        if v < -16 or v > 64:
+            flags += "l"
+            break
+    return op + ("/" + flags if flags else "")
+
+
+def pipes_table(emu, n, prices_path, cycles_per_byte):
+    """The loop's executed instructions by opcode form (per output byte), and -- with the measured issue cost of each form (pipe cycles per
+    wave64 instruction at the pipe's peak: experiments/microbench/pipe_peaks.hip, profiles/r05_pipe_peaks.txt) -- the cycles per output byte
+    each issue pipe of a SIMD is busy for ONE wave; four waves share a SIMD, so utilisation = 4 x that / the cycles a byte takes a wave."""
+    import json
+    c, tk = emu.counts()
+    hist = {}
+    for i, text in enumerate(emu.prog.text):
+        if c[i]:
+            f = form_of(text)
+            hist[f] = hist.get(f, 0) + int(c[i])
+    prices = json.load(open(prices_path)) if prices_path and os.path.exists(prices_path) else None
+    pipe = {"valu": 0.0, "salu": 0.0, "branch": 0.0}
+    unknown = {}
+    print("%-34s %9s %9s" % ("form", "instr/B", "cycles/B"))
+    for f, k in sorted(hist.items(), key=lambda kv: -kv[1]):
+        cyc = None
+        if prices:
+            cls = "valu" if f.startswith("v_") else "branch" if f.startswith(("s_cbranch", "s_branch", "s_setpc", "s_call")) else "salu" if f.startswith("s_") else None
+            pr = prices["forms"].get(f, prices["forms"].get(f.split("/")[0]))
+            if cls and pr is None:
+                pr = prices["default"][cls]
+                unknown[f] = k / n
+            if cls:
+                cyc = pr * k / n
+                pipe[cls] += cyc
+        if k / n >= 0.02:
+            print("%-34s %9.3f %9s" % (f, k / n, "%.2f" % cyc if cyc is not None else ""))
+    if prices:
+        taken = sum(int(x) for x in tk) / n
+        pipe["branch"] += taken * prices.get("taken_extra", 0.0)
+        print("pipe cycles per output byte for one wave: " + "  ".join("%s %.1f" % kv for kv in pipe.items()))
+        if cycles_per_byte:
+            print("utilisation at four waves per SIMD and %.0f cycles per byte per wave: " % cycles_per_byte +
+                  "  ".join("%s %.0f %%" % (k, 400.0 * v / cycles_per_byte) for k, v in pipe.items()))
+        if unknown:
+            print("(priced at the class default: " + ", ".join("%s %.3f" % kv for kv in sorted(unknown.items(), key=lambda kv: -kv[1])) + ")")
+    return hist, pipe
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1 << 20)
@@ -119,6 +182,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="average over this many streams (indices index .. index + streams - 1)")
     ap.add_argument("--sections", default="", help="write the per-section / per-role table (instructions per output byte) to this JSON file and print it")
     ap.add_argument("--cost", action="store_true", help="estimated cycles per output byte by section, from the measured price of each kind of instruction")
+    ap.add_argument("--pipes", action="store_true", help="executed instructions by opcode form; with --prices: pipe cycles per byte")
+    ap.add_argument("--prices", default=os.path.join(ROOT, "profiles", "r05_pipe_prices.json"))
+    ap.add_argument("--cycles-per-byte", type=float, default=0.0, help="measured cycles one output byte takes a wave (kernel ms x clock / stream size)")
     ap.add_argument("--json", default="", help="also write the mix to this file (bench.py reads profiles/r03_instruction_mix_<config>.json)")
     a = ap.parse_args()
     emu = None
@@ -159,6 +225,8 @@ def main():
         sections_table(emu, n, a, executed)
     if a.cost:
         cost_table(emu, n)
+    if a.pipes:
+        pipes_table(emu, n, a.prices, a.cycles_per_byte)
     if a.regions:
         c, tk = emu.counts()
         reg = {}

@@ -65,7 +65,7 @@ STORE_MOD = os.environ.get("MILZMA_GEN_STORE_MOD", "")  # ... of the literal / m
 WAITPROF = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "1"   # tuning: s_memtime around the two s_waitcnt vmcnt(0) sites
 WAITPROF2 = os.environ.get("MILZMA_GEN_WAITPROF", "0") == "2"  # tuning: isolated round trips of a literal's byte store / a match's load
 # sensitivity probes (tuning only): k dead scalar / vector / never-taken-branch instructions per adaptive decision
-PAD_S = int(os.environ.get("MILZMA_GEN_PAD_S", "0"))
+PAD_S = int(os.environ.get("MILZMA_GEN_PAD_S", "0"))   # (writes s96: free unless ALIGNLAZY / WAITPROF)
 PAD_V = int(os.environ.get("MILZMA_GEN_PAD_V", "0"))
 PAD_B = int(os.environ.get("MILZMA_GEN_PAD_B", "0"))
 # wave priority rotation: the SIMD's issue arbiter serves the oldest wave first, which (measured, per-wave clocks) lets the
@@ -156,6 +156,16 @@ EARLYLDS = os.environ.get("MILZMA_GEN_EARLYLDS", "1") == "1"
 # MLGUARD: a matched literal's two distance checks (lzma.rs:541-546) behind the match guard gdist (<= min(len, dict_size)): one compare
 # instead of three; the exact checks out of line.
 MLGUARD = os.environ.get("MILZMA_GEN_MLGUARD", "1") == "1"
+# Round 5 (profiles/r05_kernel_ab.txt; the pipes' prices: profiles/r05_pipe_peaks.txt -- a v_readlane occupies the vector pipe for 8 cycles, a
+# multiply / VOP3 / scalar-operand instruction for 4, a scalar instruction the CU's scalar pipe for 4 of the SIMD's cycles):
+#   S1: list of site kinds (single) whose decision is all scalar -- the node's probability by v_readlane, s_lshr + s_mul_i32 for the bound:
+#       1 vector + 6 scalar instructions instead of 3 + 4 ("mixed forms that balance the pipes")
+#   FORMA2: the deferred-update tree walks in form A (one v_readlane, range - bound and both selects on the scalar ALU: 3 vector + 6 scalar
+#       instead of 5 + 4) WITH the shadows form B has (the old form A path flushed the queue and carried an s_nop)
+#   K24S: the constant 2^24 of the normalisation tests in an SGPR (4-byte s_cmp instead of 8-byte: 3.2 tests per byte)
+S1 = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_S1", ""))))
+FORMA2 = os.environ.get("MILZMA_GEN_FORMA2", "0") == "1"
+K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
@@ -168,7 +178,7 @@ if "1" in NORM_S:
 # ---- physical temporaries (listed as clobbers; never live across the asm statement) ----------------
 S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78", n0="s79", n1="s80",
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
-         pad="s69", nb="s69", asym="s96", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
+         pad="s96", nb="s69", asym="s96", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
 MPAIR = "s[98:99]"  # a second lane mask
 DM = "s[90:91]"     # lane mask of a deferred tree update (the constants 2017 / 2048 that used to live there are VGPRs now)
@@ -179,10 +189,9 @@ _V0 = dict(M0=84, M1=85, M2=86, M3=87, VT0=88, VT1=89, VT2=90, VA=91, VPS=92, vt
            VLANE64=99, VLANE128=100, VLANE192=101, vb=102, VSH6=103, VSH6M1=104, VSH5=105, VSH5M1=106, VSH4=107, VSH4M1=108,
            VLEVEL=109, va=110, vr=112, VLANEM1=113,
            DVT=114, DVA=115, DVX=116, c2017=117, c2048=118, VSTT=119, VCH=111, VNDN=119, VB2=97)   # (VSTT only with STATE_TBL, vpad only with PAD_V)  # temporaries of deferred updates; the constants 2017 and 2048
-NBPRE = NBPRE and EOFWRAP and not PAD_S
+NBPRE = NBPRE and EOFWRAP
 if PAD_V:
-    _V0["vpad"] = 111
-    DISPMAD = False
+    _V0["vpad"] = _V0["VT2"]        # (never live across a decision: the dead-instruction probes leave the loop itself as it ships)
 if STATE_TBL:
     DISPMAD = False
 DISP2 = DISP2 and DISPMAD and DIRECT8 and NORM_S >= {"tree", "single", "lit", "direct"}   # (VB2 is VKTOP's register: free when every test is scalar)
@@ -444,7 +453,7 @@ class Gen:
             self.flush()          # (the stub branches to `to` as well: both must arrive with what the label expects)
         with self.at(role="normtest"):
             if kind in NORM_S:
-                self.e("s_cmp_lt_u32 {range}, 0x1000000")
+                self.e("s_cmp_lt_u32 {range}, " + ("{pad}" if K24S else "0x1000000"))
                 self.e("s_cbranch_scc1 " + self.L(k))
             else:
                 self.e("v_cmp_lt_u32 vcc, {range}, {VKTOP}")     # all lanes agree
@@ -484,7 +493,7 @@ class Gen:
         for _ in range(PAD_V):
             self.e("v_mov_b32 {vpad}, 0")
         for _ in range(PAD_B):
-            self.e("s_cbranch_execz " + self.L("finish"))
+            self.e("s_cbranch_execz " + self.L("Xeof"))     # (never taken; Xeof accepts any queue state)
 
     @role("core")
     def core(self, T, ln, half=None, cmp_lane=None, formb=False):
@@ -512,6 +521,20 @@ class Gen:
             mask()
             self.e("s_sub_u32 {sc1}, {code}, {range}")               # SCC = code < bound  <=>  bit == 0
             self.e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
+            return
+        if half is None and "single" in S1:
+            # all scalar: the node's probability itself is read out, the bound is s_mul_i32's
+            self.e("v_readlane_b32 {n1}, {T}, {ln}", T=T, ln=ln)
+            self.shadow(SHADOW)
+            self.flush_reads(vcc=True, sym=True)
+            self.shadow_s()
+            mask()
+            self.e("s_lshr_b32 {st}, {range}, 11")
+            self.e("s_mul_i32 {sb}, {st}, {n1}")
+            self.e("s_sub_u32 {sr1}, {range}, {sb}")
+            self.e("s_sub_u32 {sc1}, {code}, {sb}")          # SCC = code < bound  <=>  bit == 0
+            self.e("s_cselect_b32 {range}, {sb}, {sr1}")
+            self.e("s_cselect_b32 {code}, {code}, {sc1}")
             return
         # form A: every lane computes the bound of its own probability; the one that is needed is read out
         rs = ("lit" if half is not None else "single") in R11S
@@ -617,6 +640,22 @@ class Gen:
             self.shadow_s()
             e("s_sub_u32 {sc1}, {code}, {range}")                    # SCC = code < bound  <=>  bit == 0
             e("s_cselect_b64 " + RC + ", " + RC + ", " + RC1)
+            e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
+            self.norm(kind="tree")
+            return
+        if FORMA2:
+            e("v_lshrrev_b32 {vt}, 11, {range}")
+            e("v_mul_u32_u24 {vb}, {vt}, {T}", T=T)
+            if not self.shadow(1):                                   # (one instruction between vb's producer and the v_readlane of it)
+                e("s_nop 0")
+            e("v_readlane_b32 {sb}, {vb}, {ln}", ln=ln)
+            self.shadow(SHADOW - 1)
+            self.flush_reads(sym=True)
+            self.shadow_s()
+            e("s_sub_u32 {sr1}, {range}, {sb}")
+            e("s_sub_u32 {sc1}, {code}, {sb}")                       # SCC = code < bound  <=>  bit == 0
+            e("s_cselect_b32 {range}, {sb}, {sr1}")
+            e("s_cselect_b32 {code}, {code}, {sc1}")
             e("s_cselect_b32 {sym}, 3, 2" if first else "s_addc_u32 {sym}, {sym}, {sym}")
             self.norm(kind="tree")
             return
@@ -1452,6 +1491,9 @@ class Gen:
         e("v_mov_b32 {c2017}, 2017")
         e("v_mov_b32 {c2048}, 0x800")
         e("v_add_u32 {VLANEM1}, -1, {v_lane}")
+        if K24S:
+            assert not PAD_S and not ALIGNLAZY and not (WAITPROF or WAITPROF2)
+            e("s_mov_b32 {pad}, 0x1000000")
         if self.lazy:
             e("s_mov_b32 {asym}, 0")
         if DISPMAD and DIRECT8:
