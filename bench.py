@@ -51,8 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 CUS, CLOCK_GHZ = 256, 2.4
-PROFILE_ROUND = "r04"   # profiles/<round>_pmc_<config>.json and _instruction_mix_<config>.json are read only if their kernel hash is this build's
-SALU_IPC, CHAIN_IPC = 1.72, 1.71  # measured issue ceilings per CU per cycle at 16 waves/CU (profiles/r02_chain_latency.txt)
+PROFILE_ROUND = "r05"   # profiles/<round>_pmc_<config>.json and _instruction_mix_<config>.json are read only if their kernel hash is this build's
 
 PROPS = (3, 0, 2)  # lc, lp, pb of the generated .lzma streams (--props; the forked compression workers inherit it)
 
@@ -183,7 +182,22 @@ def build_batch(n_items, size, kind, dict_size, first_index, processes, mode="lz
     seconds).  Offsets are relative to the returned blob / to output offset 0."""
     import lzma_rs_amd as M
     t0 = time.time()
-    comps, crcs = compress_items(mode, n_items, size, kind, dict_size, first_index, processes)
+    # MILZMA_BENCH_CACHE=<dir>: the compressed items of a recipe are kept there (profiling calls run the same bench command once per counter
+    # set: the generation of 512 x 1 MiB costs more than the pass itself -- VERDICT r4, weak 6)
+    cache = os.environ.get("MILZMA_BENCH_CACHE")
+    cpath = os.path.join(cache, "bench_%s_%d_%d_%s_%d_%d_%s_%d.pkl" % (mode, n_items, size, kind, dict_size, first_index, "".join(map(str, PROPS)), int(KNOWN_SIZE))) if cache else None
+    if cpath and os.path.exists(cpath):
+        import pickle
+        with open(cpath, "rb") as f:
+            comps, crcs = pickle.load(f)
+    else:
+        comps, crcs = compress_items(mode, n_items, size, kind, dict_size, first_index, processes)
+        if cpath:
+            import pickle
+            os.makedirs(cache, exist_ok=True)
+            with open(cpath + ".tmp", "wb") as f:
+                pickle.dump((comps, crcs), f)
+            os.replace(cpath + ".tmp", cpath)
     units_l, blobs, in_off, out_off, comp_total, starts = [], [], 0, 0, 0, []
     for comp in comps:
         starts.append(in_off)
@@ -272,32 +286,39 @@ def cpu_baseline(size, kind, dict_size, cores):
 
 
 
-def issue_roofline(config, kind, out_bytes, k_ms, khash):
-    """The decode kernel against the measured instruction-issue ceiling of its own decision chain (what binds it), from the exact
-    executed-instruction mix of this workload (tools/emu/profile.py over 16 streams); None if the recorded mix belongs to
-    another kernel source or workload."""
+def issue_roofline(config, kind, out_bytes, k_ms, khash, units=4096):
+    """What binds the decode kernel, in hardware units: how busy the issue pipes of a SIMD are.  The exact executed-instruction mix of this
+    workload (tools/emu/profile.py over 16 streams), every instruction at the measured issue cost of its form (cycles of its pipe one
+    wave64 instruction occupies when the pipe runs at its peak: experiments/microbench/pipe_peaks.hip, profiles/r05_pipe_prices.json),
+    against the cycles the launch took; None if the recorded mix belongs to another kernel source or workload."""
     mix_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_instruction_mix_%s.json" % config)
     if kind != "text" or not os.path.exists(mix_path):
         return None
     with open(mix_path) as f:
         mix = json.load(f)
-    if mix.get("kernel_source_sha256") != khash:
+    pc = mix.get("pipe_cycles_per_output_byte")
+    if mix.get("kernel_source_sha256") != khash or not pc:
         return None
     pb = mix["per_output_byte"]
-    s_rate = pb["salu"] * out_bytes / (k_ms * 1e-3)
-    i_rate = pb["total"] * out_bytes / (k_ms * 1e-3)
-    return {"bound": "instruction_issue", "achieved": round(i_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * CHAIN_IPC, 1),
-            "unit": "G instructions/s", "frac": round(i_rate / 1e9 / (CUS * CLOCK_GHZ * CHAIN_IPC), 4),
+    waves_per_simd = min(units, CUS * 16) / float(CUS * 4)          # one wave per unit, 16 resident waves per CU
+    cyc = k_ms * 1e-3 * CLOCK_GHZ * 1e9 / (out_bytes / float(units)) # cycles one output byte takes a wave
+    busy = {k: waves_per_simd * pc[k] / cyc for k in ("valu", "salu", "branch")}
+    sb = busy["salu"] + busy["branch"]
+    return {"bound": "issue pipes of a SIMD (vector ALU; scalar ALU + branch, the CU's scalar pipe as seen from one SIMD)",
+            "unit": "busy fraction of the pipe", "peak": 1.0, "achieved": round(max(busy["valu"], sb), 4), "frac": round(max(busy["valu"], sb), 4),
+            "valu_busy": round(busy["valu"], 4), "salu_busy": round(busy["salu"], 4), "branch_busy": round(busy["branch"], 4),
+            "salu_plus_branch_busy": round(sb, 4), "binding_pipe": "valu" if busy["valu"] > sb else "salu+branch",
+            "pipe_cycles_per_output_byte_per_wave": pc, "cycles_per_output_byte_per_wave": round(cyc, 1), "waves_per_simd": waves_per_simd,
+            "clock_ghz": CLOCK_GHZ,
             "instructions_per_output_byte": pb["total"], "salu_per_output_byte": pb["salu"],
             "valu_per_output_byte": pb["valu"], "branch_per_output_byte": pb["branch"],
-            "scalar_only": {"achieved": round(s_rate / 1e9, 2), "peak": round(CUS * CLOCK_GHZ * SALU_IPC, 1),
-                            "frac": round(s_rate / 1e9 / (CUS * CLOCK_GHZ * SALU_IPC), 4)},
-            "note": "the peak is a MEASURED ceiling of this kernel's own decision chain at the occupancy 4096 streams give (4 waves per "
-                    "SIMD: 1.71 instructions per cycle per CU; experiments/microbench/chain_latency.hip, profiles/r02_chain_latency.txt), "
-                    "not a data-sheet number and not what the hardware can issue: the same chain reaches 2.42 at 8 waves per SIMD, which "
-                    "would need 8192 streams and <= 64 VGPRs.  frac ~ 1 says the kernel runs as fast as its instruction stream can be "
-                    "issued one wave per stream; only a shorter stream makes it faster.  Instruction counts: exact, the kernel's symbol "
-                    "loop executed in tools/emu on 16 streams of this workload (" + os.path.basename(mix_path) + ")"}
+            "hardware_peaks": "per SIMD: one vector instruction per 2.3 cycles on vector registers / inline constants, per 4.3 with an SGPR operand, a "
+                              "multiply or a VOP3 encoding, per 8.3 for a v_readlane whose lane select is an SGPR (4.3 with the lane in m0); one scalar "
+                              "instruction per 4.1 cycles (= one per cycle per CU); a never-taken branch behind its compare +1.7",
+            "note": "busy = waves per SIMD x pipe cycles per byte / cycles per byte.  Both pipes of every SIMD are busy for most of the launch: the "
+                    "kernel is bound by instruction issue, and what is left is the arbitration loss of four in-order waves per SIMD (a fifth wave "
+                    "adds 2.9 %, DESIGN.md section 4).  Instruction counts: exact, the kernel's symbol loop executed in tools/emu on 16 streams "
+                    "of this workload (" + os.path.basename(mix_path) + "); prices: profiles/r05_pipe_prices.json"}
 
 
 def pmc_traffic(config, khash):
@@ -415,7 +436,7 @@ def run_other_config(name, args, M, torch, dev, ctx, procs, steps, warmup):
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": alg,
                          "traffic": pmc_traffic(name, kernel_source_hash())[0],
                          "traffic_recorded_on": pmc_traffic(name, kernel_source_hash())[1]},
-            "roofline_issue": issue_roofline(name, "text", out_bytes, k_ms, kernel_source_hash())}
+            "roofline_issue": issue_roofline(name, "text", out_bytes, k_ms, kernel_source_hash(), units=n * upi)}
 
 
 def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
@@ -986,7 +1007,7 @@ def main():
             traffic_note = "profiles/%s_pmc_%s.json was taken with another kernel source (%s)" % (PROFILE_ROUND, args.config, pmc.get("kernel_source_sha256"))
     alg_bytes = comp_total + out_bytes_rank  # per launch on this rank: compressed read once + output written once
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    scalar = issue_roofline(args.config, args.kind, out_bytes_rank, k_ms, khash)
+    scalar = issue_roofline(args.config, args.kind, out_bytes_rank, k_ms, khash, units=n_units)
 
     if rank == 0:
         what = ("%d .xz files of %d B per GPU (1 MiB blocks, LZMA2 with stored chunks, CRC64): %d LZMA2 units" % (n, size, n_units)

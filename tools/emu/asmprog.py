@@ -265,6 +265,140 @@ class AsmLoop:
         for k, w in enumerate((base & 0xFFFFFFFF, (base >> 32) & 0xFFFF, records, 0x00020000)):
             self.L.emu_set_s(self.h, i + k, w)
 
+
+    def _reset_model(self, lane):
+        """reset_model: every probability 0x400 (registers and the LDS rows), the row caches empty"""
+        G = self.G
+        for name in G.OPS_INOUT_V:
+            if name.startswith("m_") or name in ("u0", "u1", "u2", "u3"):
+                self.vset(self._vidx(name), 0x400)
+        for i in range(self.lit_regs):
+            self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
+        for i in range(4):
+            self.vset(self.ps0 + i, 0x400)
+        lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
+        self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
+        self.vset(self._vidx("v_lane"), lane)
+        self.vset(self._vidx("pend_val"), 0)
+        if "vtag" in self.regmap:   # (the walked row 0 owns its slot; everything else empty)
+            self.vset(self._vidx("vtag"), np.where(lane == 0, 0, 0xFFFFFFFF).astype(np.uint32))
+            self.vset(self._vidx("vtagm"), 0xFFFFFFFF)
+
+    # ---- an LZMA2 unit: the packet walk of decode_unit (lzma2.rs:52-229) around the same loop -- well-formed streams of the fast class only
+    #      (lc + lp <= 3; what bench.py's .xz recipe holds): the instruction mix of configs[3], not an error-path mirror -------------------------
+    def decode_lzma2(self, data, out_cap, max_steps=1 << 40):
+        """Returns dict(status, out, executed, chunks).  Stored chunks are copied by the front end (the kernel's C++ does that); every LZMA
+        chunk runs in the loop with a fresh range coder, the model / state reset as its control byte says."""
+        G = self.G
+        data = bytes(data)
+        IN0 = 64
+        in_span = (len(data) + 63 + 128) & ~63
+        OUT0 = IN0 + in_span + 64
+        mem = np.zeros(OUT0 + out_cap + 1024, dtype=np.uint8)
+        mem[IN0:IN0 + len(data)] = np.frombuffer(data, dtype=np.uint8)
+        mem[0] = 1
+        if "flagptr" in self.regmap:
+            i = self._sidx("flagptr")
+            self.L.emu_set_s(self.h, i, 0)
+            self.L.emu_set_s(self.h, i + 1, 0)
+        self._mem = mem
+        self.L.emu_set_mem(self.h, mem.ctypes.data, mem.size)
+        self.L.emu_set_hwreg(self.h, 0)
+        lane = np.arange(64, dtype=np.uint32)
+        S = self.sset
+        self._reset_model(lane)
+        S("len", 0)
+        S("state", 0)
+        for r in ("rep0", "rep1", "rep2", "rep3"):
+            S(r, 0)
+        S("cur_row", 0)
+        S("mlen", 0)
+        for p in ("prof_wm", "prof_nm", "prof_wc", "prof_nc"):
+            S(p, 0)
+        S("ldsbase", 0)
+        S("qtop", 0xFFFFFFFF)
+        S("known", 1)
+        S("dict_size", 1 << 26)            # (the XZ filter's dictionary bounds distances; well-formed input: never reached)
+        S("out_lim", out_cap)
+        S("safe_len", out_cap - 273 if out_cap >= 273 else 0)
+        self.set_rsrc("out_rsrc", OUT0, out_cap)
+        pos, executed, chunks, have_props = 0, 0, 0, False
+        while True:
+            c = data[pos]
+            if c == 0:
+                return dict(status=ST_OK, out=mem[OUT0:OUT0 + self.sget("len")].tobytes(), executed=executed, chunks=chunks, in_consumed=pos + 1)
+            if c < 0x80:                   # stored chunk (1: dictionary reset, 2: none)
+                n = ((data[pos + 1] << 8) | data[pos + 2]) + 1
+                ln = self.sget("len")
+                mem[OUT0 + ln:OUT0 + ln + n] = np.frombuffer(data[pos + 3:pos + 3 + n], dtype=np.uint8)
+                S("len", ln + n)
+                pos += 3 + n
+                continue
+            unpacked = (((c & 0x1F) << 16) | (data[pos + 1] << 8) | data[pos + 2]) + 1
+            packed = ((data[pos + 3] << 8) | data[pos + 4]) + 1
+            hdr = 5
+            if c >= 0xC0:
+                props = data[pos + 5]
+                hdr = 6
+                lc, lp, pb = props % 9, (props // 9) % 5, props // 45
+                assert lc + lp <= 3 and pb <= 2, "the front end mirrors the LP0 / GEN variants only"
+                S("lc", lc)
+                S("lc8", 8 - lc)
+                S("lpmask", (1 << lp) - 1)
+                S("pbmask", (1 << pb) - 1)
+                have_props = True
+            assert have_props
+            if c >= 0xA0:                  # state reset (with or without new properties)
+                self._reset_model(lane)
+                S("state", 0)
+                for r in ("rep0", "rep1", "rep2", "rep3"):
+                    S(r, 0)
+                S("cur_row", 0)
+            payload = data[pos + hdr:pos + hdr + packed]
+            base = IN0 + pos + hdr
+
+            def window(wpos, payload=payload):
+                w = np.zeros(64, dtype=np.uint32)
+                seg = payload[wpos:wpos + 64]
+                w[:len(seg)] = np.frombuffer(seg, dtype=np.uint8) if seg else 0
+                return w
+
+            self.set_rsrc("in_rsrc", base, packed)
+            self.vset(self._vidx("winb"), window(0))
+            self.vset(self._vidx("winb_next"), window(64))
+            S("range", 0xFFFFFFFF)
+            S("code", int.from_bytes(payload[1:5], "big"))
+            S("off", 5)
+            S("lim", packed)
+            S("wbase", 0)
+            S("prev", 0)
+            S("mb", 0xFFFFFFFF)
+            S("pend_n", G.PEND_UNKNOWN if self.sget("len") else 0)     # (the previous byte is fetched from the output by the loop's entry)
+            S("pend_pos", 0)
+            S("exitcode", 0)
+            S("tbl_ready", 0)
+            S("target", self.sget("len") + unpacked)
+            while True:
+                n = self.L.emu_run(self.h, 0, max_steps)
+                if n < 0:
+                    raise RuntimeError("emulator: " + self.L.emu_error(self.h).decode())
+                executed += n
+                ex = self.sget("exitcode") & 0xFF
+                S("exitcode", ex)
+                if ex != G.EXIT["LZ_SLOW"]:
+                    break
+                ln, mlen, dist = self.sget("len"), self.sget("mlen"), self.sget("rep0") + 1
+                for i in range(mlen):
+                    mem[OUT0 + ln + i] = mem[OUT0 + ln - dist + i]
+                S("pend_n", G.PEND_UNKNOWN)
+                S("mb", 0xFFFFFFFF)
+                S("len", ln + mlen)
+            if ex != G.EXIT["DONE_SIZE"]:
+                name = {v: k for k, v in G.EXIT.items()}[ex]
+                return dict(status=name, out=mem[OUT0:OUT0 + self.sget("len")].tobytes(), executed=executed, chunks=chunks, in_consumed=pos)
+            chunks += 1
+            pos += hdr + packed
+
     # ---- the kernel around the loop (decode_fast_asm.hip.h), raw LZMA units only ------------------------------
     def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None):
         """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode).
@@ -300,21 +434,7 @@ class AsmLoop:
                     w[l] = payload[wpos + l]
             return w
 
-        # model reset (reset_model)
-        for name in G.OPS_INOUT_V:
-            if name.startswith("m_") or name in ("u0", "u1", "u2", "u3"):
-                self.vset(self._vidx(name), 0x400)
-        for i in range(self.lit_regs):
-            self.vset(getattr(G, "VBASE", 64) + i, 0x04000400)
-        for i in range(4):
-            self.vset(self.ps0 + i, 0x400)
-        lds = np.full(self.lit_regs // 2 * 64 * 4, 0x04000400, dtype=np.uint32)
-        self.L.emu_lds_write(self.h, 0, lds.ctypes.data, lds.size * 4)
-        self.vset(self._vidx("v_lane"), lane)
-        self.vset(self._vidx("pend_val"), 0)
-        if "vtag" in self.regmap:   # (the walked row 0 owns its slot; everything else empty)
-            self.vset(self._vidx("vtag"), np.where(lane == 0, 0, 0xFFFFFFFF).astype(np.uint32))
-            self.vset(self._vidx("vtagm"), 0xFFFFFFFF)
+        self._reset_model(lane)
         if "lit_rsrc" in self.regmap:
             self.set_rsrc("lit_rsrc", SLAB0, slab_bytes)
         # reader: seek(0, in_len), then rc_init

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import asmprog  # noqa: E402
 from lzma_rs_amd import workloads as W  # noqa: E402
 
@@ -119,7 +120,12 @@ def form_of(text):
         return op
     flags = ""
     srcs = ops[1:]
-    if any(re.match(r"^(s\d+|s\[\d+:\d+\]|vcc|m0|exec)$", o) for o in srcs):
+    import gen_fast_loop as G
+    scalar_names = set(G.OPS_INOUT_S) | set(G.OPS_IN_S)
+    srcs = ["s0" if (o.startswith("%[") and o[2:-1] in scalar_names) else o for o in srcs]   # (asm operands the compiler places: scalar ones count as SGPRs)
+    if op.startswith("v_readlane") and srcs[-1] == "m0":
+        flags += "m0"        # (the lane select in m0 does not go through the SGPR file: priced like a constant lane)
+    elif any(re.match(r"^(s\d+|s\[\d+:\d+\]|vcc|m0|exec)$", o) for o in srcs):
         flags += "s"
     for o in srcs:
         try:
@@ -132,7 +138,7 @@ def form_of(text):
     return op + ("/" + flags if flags else "")
 
 
-def pipes_table(emu, n, prices_path, cycles_per_byte):
+def pipes_table(emu, n, prices_path, cycles_per_byte, quiet=False):
     """The loop's executed instructions by opcode form (per output byte), and -- with the measured issue cost of each form (pipe cycles per
     wave64 instruction at the pipe's peak: experiments/microbench/pipe_peaks.hip, profiles/r05_pipe_peaks.txt) -- the cycles per output byte
     each issue pipe of a SIMD is busy for ONE wave; four waves share a SIMD, so utilisation = 4 x that / the cycles a byte takes a wave."""
@@ -146,6 +152,11 @@ def pipes_table(emu, n, prices_path, cycles_per_byte):
     prices = json.load(open(prices_path)) if prices_path and os.path.exists(prices_path) else None
     pipe = {"valu": 0.0, "salu": 0.0, "branch": 0.0}
     unknown = {}
+    if quiet:
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            return pipes_table(emu, n, prices_path, cycles_per_byte)
     print("%-34s %9s %9s" % ("form", "instr/B", "cycles/B"))
     for f, k in sorted(hist.items(), key=lambda kv: -kv[1]):
         cyc = None
@@ -154,7 +165,8 @@ def pipes_table(emu, n, prices_path, cycles_per_byte):
             pr = prices["forms"].get(f, prices["forms"].get(f.split("/")[0]))
             if cls and pr is None:
                 pr = prices["default"][cls]
-                unknown[f] = k / n
+                if cls == "valu":
+                    unknown[f] = k / n
             if cls:
                 cyc = pr * k / n
                 pipe[cls] += cyc
@@ -185,13 +197,37 @@ def main():
     ap.add_argument("--pipes", action="store_true", help="executed instructions by opcode form; with --prices: pipe cycles per byte")
     ap.add_argument("--prices", default=os.path.join(ROOT, "profiles", "r05_pipe_prices.json"))
     ap.add_argument("--cycles-per-byte", type=float, default=0.0, help="measured cycles one output byte takes a wave (kernel ms x clock / stream size)")
+    ap.add_argument("--config", default="", help="bench.py's recipe of that name (lzma64k, dict8m, xz: the .xz files' blocks -- LZMA2 units -- through "
+                                                 "the front end's packet walk) instead of --kind / --size / --dict")
     ap.add_argument("--json", default="", help="also write the mix to this file (bench.py reads profiles/r03_instruction_mix_<config>.json)")
     a = ap.parse_args()
     emu = None
     tot = {}
     executed = comp_bytes = 0
     t = time.time()
+    xz = a.config == "xz"
+    if a.config:
+        import bench
+        cfg = bench.CONFIGS[a.config]
+        a.kind, a.size, a.dict = "text", cfg["size"], cfg["dict"]
     for index in range(a.index, a.index + a.streams):
+        if xz:   # one .xz file of the recipe: every block's LZMA2 payload is one decode unit (milzma_xz_plan, as bench.py plans them)
+            import bench
+            import lzma_rs_amd as M
+            plain = bench.xz_plain(index, a.size)
+            comp = W.compress_xz_blocks(plain, block_size=1 << 20, dict_size=a.dict, check="crc64")
+            units, _ = M.xz_plan(comp)
+            if emu is None:
+                emu = asmprog.AsmLoop(lp0=True)
+            got = b""
+            for u in units:
+                r = emu.decode_lzma2(comp[u.in_off:u.in_off + u.in_len], int(u.out_cap) + 300)
+                assert r["status"] == "OK", r["status"]
+                got += r["out"]
+                executed += r["executed"]
+                comp_bytes += int(u.in_len)
+            assert got == plain
+            continue
         plain = W.make_plain(a.kind, a.size, seed=W.SEED0 ^ index)
         comp = W.compress_alone(plain, dict_size=a.dict, known_size=True)
         props = comp[0]
@@ -209,6 +245,9 @@ def main():
     print("%s %d x %d B, dict %d: compressed %d B, %d instructions executed (%.1f s), bit-exact"
           % (a.kind, a.streams, a.size, a.dict, comp_bytes, executed, time.time() - t))
     print("per output byte: " + "  ".join("%s %.2f" % (k, mix[k] / n) for k in ("salu", "valu", "branch", "misc", "lds", "vmem", "total", "taken") if k in mix))
+    pipes = None
+    if a.pipes or a.json:
+        _, pipes = pipes_table(emu, n, a.prices, a.cycles_per_byte, quiet=not a.pipes)
     if a.json:
         import json
         import bench
@@ -219,14 +258,17 @@ def main():
                        "how": "tools/emu/profile.py: the generated symbol loop executed instruction by instruction on the CPU "
                               "(bit-exact output), every executed instruction counted by class, averaged over the streams",
                        "per_output_byte": {k: round(mix.get(k, 0) / n, 4) for k in ("salu", "valu", "branch", "misc", "lds", "vmem", "total", "taken")},
+                       "pipe_cycles_per_output_byte": {k: round(v, 2) for k, v in (pipes or {}).items()},
+                       "pipe_cycles_how": "every executed instruction at the measured issue cost of its form (cycles of its pipe one wave64 instruction "
+                                          "occupies at the pipe's peak: profiles/r05_pipe_prices.json, experiments/microbench/pipe_peaks.hip); one wave's "
+                                          "share -- four waves share a SIMD's vector pipe and its turn on the CU's scalar pipe",
                        "executed_instructions": executed, "compressed_bytes": comp_bytes}, f, indent=1)
             f.write("\n")
     if a.sections:
         sections_table(emu, n, a, executed)
     if a.cost:
         cost_table(emu, n)
-    if a.pipes:
-        pipes_table(emu, n, a.prices, a.cycles_per_byte)
+
     if a.regions:
         c, tk = emu.counts()
         reg = {}

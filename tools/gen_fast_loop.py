@@ -163,6 +163,12 @@ MLGUARD = os.environ.get("MILZMA_GEN_MLGUARD", "1") == "1"
 #   FORMA2: the deferred-update tree walks in form A (one v_readlane, range - bound and both selects on the scalar ALU: 3 vector + 6 scalar
 #       instead of 5 + 4) WITH the shadows form B has (the old form A path flushed the queue and carried an s_nop)
 #   K24S: the constant 2^24 of the normalisation tests in an SGPR (4-byte s_cmp instead of 8-byte: 3.2 tests per byte)
+#   SYM_M0: the running symbol of a tree walk lives in m0 -- it is the lane select of the walk's v_readlane, and a v_readlane whose lane comes from
+#       an SGPR occupies the vector pipe for 8 cycles where one with a constant lane takes 4 (profiles/r05_pipe_peaks.txt); m0 is not read
+#       through the SGPR file.  (s_set_gpr_idx_on writes m0: the two places where the symbol was still live across one are re-ordered.)
+SYM_M0 = os.environ.get("MILZMA_GEN_SYM_M0", "1") == "1"   # (round 5: 238.3 -> 222.4 ms, profiles/r05_kernel_ab.txt)
+SYM_M0 = SYM_M0 and "wb" not in SSHADOW and not ALIGNLAZY and not LENDEFER   # (round 4's rejected knobs keep the symbol, or a queued
+#                                                                              update that reads it, live across an s_set_gpr_idx_on)
 S1 = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_S1", ""))))
 FORMA2 = os.environ.get("MILZMA_GEN_FORMA2", "0") == "1"
 K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
@@ -170,7 +176,7 @@ VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
-SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "4"))
+SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "6"))   # (round 5: 6 instead of 4: -0.4 %, with and without SYM_M0)
 if "1" in NORM_S:
     NORM_S = {"tree", "single", "lit", "direct"}
 
@@ -180,6 +186,9 @@ S = dict(sp="s72", sb="s73", sr1="s74", sc1="s75", sk="s76", ln="s77", sym="s78"
          ps="s81", row="s82", t0="s83", t1="s84", t2="s85", t3="s86", t4="s87", t5="s88", t6="s89",
          pad="s96", nb="s69", asym="s96", st="s72", prioph="s68", jb_lo="s64", jb_hi="s65", pl0="s97", gtop="s70", gdist="s71",
          clk_lo="s94", clk_hi="s95", clk_t="s96")  # s[94:95] / s96: s_memtime of the priority rotation and of the wait profiles
+S["lnm"] = S["ln"]   # the lane of the is_match decision: no tree walk is in progress at a symbol's top, so m0 is free for it too
+if SYM_M0:
+    S["sym"] = S["lnm"] = "m0"
 MPAIR = "s[98:99]"  # a second lane mask
 DM = "s[90:91]"     # lane mask of a deferred tree update (the constants 2017 / 2048 that used to live there are VGPRs now)
 JPAIR, JPAIR_LO, JPAIR_HI = "s[98:99]", "s98", "s99"  # target of the computed jump into the direct-bit chain
@@ -214,7 +223,7 @@ def set_layout():
 
 
 set_layout()
-CLOBBER_S = sorted(set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}, key=lambda r: int(r[1:]))  # (+ DM, the refill return address)
+CLOBBER_S = sorted((set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}) - {"m0"}, key=lambda r: int(r[1:]))   # (m0 cannot be listed: the compiler sets it wherever it needs it)  # (+ DM, the refill return address)
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9, QUANTUM=10)
@@ -330,6 +339,8 @@ class Gen:
                 self._edge(tgt.group(1), op != "s_branch")
         elif len(ops) > 1 and not kw.get("_queued"):
             # a queued instruction must be emitted before something it reads is overwritten
+            if S["sym"] == "m0" and (op == "s_set_gpr_idx_on" or (ops[1] == "m0" and op == "s_mov_b32")) and any(x[1] for x in self.q):
+                raise AssertionError("m0 (the symbol) is overwritten while a deferred update still reads it: " + out)
             if ops[1] == S["sym"] and any(x[1] for x in self.q):
                 raise AssertionError("sym is overwritten while a deferred update still reads it: " + out)
             if ops[1] == "vcc" and op.startswith("v_") and any(x[2] for x in self.q):
@@ -1159,8 +1170,8 @@ class Gen:
             e("s_lshl4_add_u32 {ln}, {state}, {ps}")
             self.decide_by_reg(["m_ismatch", "m_ismatch_b", "m_ismatch_c"], R("ln"), "match" + tag, "lit" + tag)
         else:
-            e("s_lshl2_add_u32 {ln}, {state}, {ps}")
-            self.decide(R("m_ismatch"), R("ln"), "match")
+            e("s_lshl2_add_u32 {lnm}, {state}, {ps}")
+            self.decide(R("m_ismatch"), R("lnm"), "match")
         with self.in_cold():
             if self.pb4:
                 lab("match" + tag + "2")
@@ -1429,14 +1440,20 @@ class Gen:
                     self.queue_s("s_set_gpr_idx_off", kind="wb")
                 written = True
             self.bit_nu(R("m_align"), "1" if i == 0 else R("sym"), first=(i == 0))
-        if not written:
-            self.posslot_writeback()
-        if self.lazy:
-            with self.at(role="update"):
-                e("s_mov_b32 {asym}, {sym}")
-        else:
+        if SYM_M0:   # (the write-back's s_set_gpr_idx_on overwrites m0: everything that reads the symbol comes first)
+            assert not written and not self.lazy
             self.tree_update(R("m_align"), 4)
-        e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
+            e("s_lshl_b32 {t3}, {sym}, 28")
+            self.posslot_writeback()
+        else:
+            if not written:
+                self.posslot_writeback()
+            if self.lazy:
+                with self.at(role="update"):
+                    e("s_mov_b32 {asym}, {sym}")
+            else:
+                self.tree_update(R("m_align"), 4)
+            e("s_lshl_b32 {t3}, {sym}, 28")                      # drops the leading 1; the inverted path, first bit on top
         e("s_brev_b32 {t3}, {t3}")                           # a'
         e("s_lshl4_add_u32 {t4}, {t4}, {t3}")
         e("s_sub_u32 {rep0}, {t2}, {t4}")                    # (0xFFFFFFFF = the end marker: caught by copy's distance guard)
@@ -1449,8 +1466,11 @@ class Gen:
             # slots 4..11: pos_decoders[result - slot + node] in m_posdec_a, ndb = 1..4 bits;
             # slots 12, 13: m_posdec_b lanes (slot - 12) * 32 + node, 5 bits
             lab("dist_rev")
+            if SYM_M0:
+                e("s_xor_b32 {t0}, {sym}, 0x7f")                # pos_slot  (read before the write-back's s_set_gpr_idx_on overwrites m0)
             self.posslot_writeback()
-            e("s_xor_b32 {t0}, {sym}, 0x7f")                    # pos_slot
+            if not SYM_M0:
+                e("s_xor_b32 {t0}, {sym}, 0x7f")                # pos_slot
             e("s_lshr_b32 {t1}, {t0}, 1")
             e("s_add_u32 {t1}, {t1}, -1")                       # num_direct_bits;  t2 = (2 | (slot & 1)) << ndb (table)
             e("s_cmp_lt_u32 {t0}, 12")
@@ -1746,14 +1766,14 @@ class Gen:
         self.sec = "is_rep"
         lab("rep_match")
         self.taken(R("m_rep"))
-        e("s_add_u32 {ln}, {state}, 12")
-        self.decide(R("m_rep"), R("ln"), "rep_123")           # is_rep_g0
+        e("s_add_u32 {lnm}, {state}, 12")
+        self.decide(R("m_rep"), R("lnm"), "rep_123")          # is_rep_g0
         if self.pb4:
             e("s_lshl4_add_u32 {ln}, {state}, {ps}")
             self.decide_by_reg(["m_rep0long", "m_rep0long_b", "m_rep0long_c"], R("ln"), "rep0_long", "rep0_short")
         else:
-            e("s_lshl2_add_u32 {ln}, {state}, {ps}")
-            self.decide(R("m_rep0long"), R("ln"), "rep0_long")    # is_rep_0long
+            e("s_lshl2_add_u32 {lnm}, {state}, {ps}")
+            self.decide(R("m_rep0long"), R("lnm"), "rep0_long")   # is_rep_0long
         e("s_cmpk_lt_u32 {state}, 7")                        # short rep
         e("s_cselect_b32 {state}, 9, 11")
         e("s_mov_b32 {mlen}, 1")
@@ -1766,16 +1786,16 @@ class Gen:
             self.taken(R("m_rep0long"), to="rep_len")
         lab("rep_123")
         self.taken(R("m_rep"))
-        e("s_add_u32 {ln}, {state}, 24")
-        self.decide(R("m_rep"), R("ln"), "rep_23")            # is_rep_g1
+        e("s_add_u32 {lnm}, {state}, 24")
+        self.decide(R("m_rep"), R("lnm"), "rep_23")           # is_rep_g1
         e("s_mov_b32 {t0}, {rep1}")
         e("s_mov_b32 {rep1}, {rep0}")
         e("s_mov_b32 {rep0}, {t0}")
         e("s_branch " + L("rep_len"))
         lab("rep_23")
         self.taken(R("m_rep"))
-        e("s_add_u32 {ln}, {state}, 36")
-        self.decide(R("m_rep"), R("ln"), "rep_3")             # is_rep_g2
+        e("s_add_u32 {lnm}, {state}, 36")
+        self.decide(R("m_rep"), R("lnm"), "rep_3")            # is_rep_g2
         e("s_mov_b32 {t0}, {rep2}")
         e("s_mov_b32 {rep2}, {rep1}")
         e("s_mov_b32 {rep1}, {rep0}")
