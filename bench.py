@@ -545,7 +545,8 @@ def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
                                   "kernel_ms_sum": round(ms_all, 3), "rounds": rounds, "units_parked": parked_total, "bit_exact": bad2 == 0},
             "roofline": {"bound": "hbm", "achieved": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                         "algorithmic_bytes_per_launch": comp_total + out_total, "traffic": None}}
+                         "algorithmic_bytes_per_launch": comp_total + out_total,
+                         "traffic": pmc_traffic("unknown_size", kernel_source_hash())[0] if (n, size) == (cfg["streams"], cfg["size"]) else None}}
 
 
 def run_inproc(args):

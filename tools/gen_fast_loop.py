@@ -203,7 +203,10 @@ if PAD_V:
     _V0["vpad"] = _V0["VT2"]        # (never live across a decision: the dead-instruction probes leave the loop itself as it ships)
 if STATE_TBL:
     DISPMAD = False
-DISP2 = DISP2 and DISPMAD and DIRECT8 and NORM_S >= {"tree", "single", "lit", "direct"}   # (VB2 is VKTOP's register: free when every test is scalar)
+# (VB2 = tbl_b >> 8 lives in VKTOP's register, which is free when every range test is scalar; with a vector-side test it is recomputed where
+#  it is used: one vector instruction per match)
+DISP2 = DISP2 and DISPMAD and DIRECT8
+VB2_INLINE = DISP2 and not NORM_S >= {"tree", "single", "lit", "direct"}
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
 LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
 
@@ -1367,7 +1370,11 @@ class Gen:
         if DISP2:
             e("s_flbit_i32_b32 {t6}, {range}")               # leading zeros of range: 0..7
             e("v_add_u32 {VT0}, {t6}, {tbl_b}")              # low byte: n + clz
-            e("v_mad_u32_u24 {VT2}, {t6}, {VCH}, {VB2}")     # B2 + clz * stride
+            if VB2_INLINE:
+                e("v_lshrrev_b32 {VT2}, 8, {tbl_b}")
+                e("v_mad_u32_u24 {VT2}, {t6}, {VCH}, {VT2}")
+            else:
+                e("v_mad_u32_u24 {VT2}, {t6}, {VCH}, {VB2}")     # B2 + clz * stride
             e("v_bfe_u32 {VT1}, {VT0}, 3, 5")
             e("v_mad_i32_i24 {VT0}, {VT1}, {VNDN}, {VT2}")
             e("s_mov_b32 {t4}, 0")
@@ -1570,7 +1577,7 @@ class Gen:
             e("v_cndmask_b32 {VSTT}, {vx}, {VSTT}, vcc")
         self.set_guards(R("n0"))
         self.tables_prologue()
-        if DISP2:
+        if DISP2 and not VB2_INLINE:
             e("v_lshrrev_b32 {VB2}, 8, {tbl_b}")
         if PRIO:
             e("s_getreg_b32 {prioph}, hwreg(HW_REG_HW_ID, 0, 4)")   # this wave's slot on its SIMD

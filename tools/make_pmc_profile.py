@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc passes of one bench workload into profiles/r04_pmc_<config>.json (what bench.py's
+"""Turns the rocprofv3 --pmc passes of one bench workload into profiles/<round>_pmc_<config>.json (what bench.py's
 roofline.traffic reads, keyed by the kernel source hash).
 
     python tools/make_pmc_profile.py <config> <dir with pass_*/**/*counter_collection.csv> <out.json>
@@ -20,7 +20,10 @@ import bench  # noqa: E402
 
 def main():
     config, src, out = sys.argv[1:4]
-    key = "decode_fast_asm_kernel"
+    # unknown_size (bench.py --unknown-size): the growable-output launch is the time-sliced kernel; the FIRST dispatch of a pass is the
+    # timed step (what follows -- the verification step, the every-guess-wrong sequence with its RESUME launches -- is not the figure)
+    first_only = config == "unknown_size"
+    key = "decode_fast_asm_sliced_kernel" if first_only else "decode_fast_asm_kernel"
     counters, dur, passes = {}, [], {}
     newest = {}          # one CSV per pass directory: the most recent (a repeated pass leaves the older attempt's file behind)
     for path in glob.glob(os.path.join(src, "pass_*", "**", "*counter_collection.csv"), recursive=True):
@@ -36,11 +39,14 @@ def main():
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         if not per:
             continue
+        if first_only:
+            first = min(per, key=lambda d: int(d))
+            per = {first: per[first]}
         name = path[len(src):].strip("/").split("/")[0]
         passes[name] = len(per)
         for c in sorted({c for d in per.values() for c in d}):
             counters[c] = sum(d.get(c, 0.0) for d in per.values()) / len(per)
-    cfg = bench.CONFIGS[config]
+    cfg = bench.CONFIGS["lzma64k" if config == "unknown_size" else config]
     out_bytes = cfg["streams"] * cfg["size"]
     derived = {}
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
@@ -68,9 +74,9 @@ def main():
                                         if k in counters}
     with open(out, "w") as f:
         json.dump({"kernel_source_sha256": bench.kernel_source_hash(), "config": config,
-                   "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py --config %s "
+                   "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py %s "
                               "--steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none "
-                              "(experiments/gpu_calls/r4_evidence.sh)" % config,
+                              "(experiments/gpu_calls/r5_evidence.sh)" % ("--unknown-size" if first_only else "--config " + config),
                    "dispatches_per_pass": passes, "kernel_ms_under_pmc": round(sum(dur) / max(1, len(dur)), 2),
                    "counters_per_launch": counters, "derived": derived}, f, indent=1)
         f.write("\n")
