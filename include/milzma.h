@@ -191,6 +191,14 @@ int milzma_decode_units_host(milzma_ctx *ctx, const milzma_unit *units, uint32_t
  * with HIP events on the launch stream, and how many kernel launches that was. */
 float milzma_last_kernel_ms(const milzma_ctx *ctx, uint32_t *launches);
 
+/* Which way the most recent whole-file batch call on this context (milzma_{lzma,lzma2,xz}_decompress_batch) sent its files -- a bit mask;
+ * for operators and tests ("did my batch take the streamed launch?"), never needed for correctness: every path hands back the same bytes. */
+#define MILZMA_PATH_STREAMED 1u        /* one streamed launch: the waves wrote the output into the result buffers while they decoded */
+#define MILZMA_PATH_TWO_PART_INPUT 2u  /* ... and its input went up in two parts (every unit's lead before the launch, the rest beside it) */
+#define MILZMA_PATH_CLASSIC 4u         /* staged upload, decode launches, staged download */
+#define MILZMA_PATH_GROUPED 8u         /* the call was cut into groups over contexts of the device (>= 8192 units, or MILZMA_LANES) */
+uint32_t milzma_last_call_paths(const milzma_ctx *ctx);
+
 /* Renders a unit result as the reference would: returns the error kind (MILZMA_OK ...
  * MILZMA_XZ_ERROR) and writes the full Display string (src/error.rs:28-36) into msg. */
 int milzma_result_message(const milzma_result *res, uint32_t unit_kind, char *msg, size_t msg_cap);

@@ -31,6 +31,10 @@ pub const MILZMA_ST_OUT_FULL: u32 = 32;
 pub const MILZMA_PARKED: u64 = 1;
 pub const MILZMA_DECODE_GROW: u32 = 1;
 pub const MILZMA_DECODE_RESUME: u32 = 2;
+pub const MILZMA_PATH_STREAMED: u32 = 1;
+pub const MILZMA_PATH_TWO_PART_INPUT: u32 = 2;
+pub const MILZMA_PATH_CLASSIC: u32 = 4;
+pub const MILZMA_PATH_GROUPED: u32 = 8;
 
 /// One independent serial decode job (one wavefront).
 #[repr(C)]
@@ -150,6 +154,7 @@ extern "C" {
         results: *mut milzma_result,
     ) -> c_int;
     pub fn milzma_last_kernel_ms(ctx: *const milzma_ctx, launches: *mut u32) -> c_float;
+    pub fn milzma_last_call_paths(ctx: *const milzma_ctx) -> u32;
     pub fn milzma_crc_units(
         ctx: *mut milzma_ctx,
         units: *const milzma_unit,

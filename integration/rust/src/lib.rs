@@ -109,11 +109,18 @@ impl Drop for MultiContext {
 
 /// Unit-level calls on memory that already lives on the device (a pipeline that keeps files and output in HBM).
 impl Context {
+    /// `milzma_last_call_paths`: which way the most recent whole-file batch call on this context sent its files
+    /// (`ffi::MILZMA_PATH_STREAMED | ..._TWO_PART_INPUT | ..._CLASSIC | ..._GROUPED`): a diagnostic, every path hands back the same bytes.
+    pub fn last_call_paths(&self) -> u32 {
+        unsafe { ffi::milzma_last_call_paths(self.raw) }
+    }
+
     /// `milzma_decode_units_ex`: `units[i]` names a slice of `d_in` / `d_out` (device pointers of this context's device).
     /// With `ffi::MILZMA_DECODE_GROW` a unit that fills its slice before its stream ends comes back as
     /// `status == MILZMA_ST_OUT_FULL` with `err_a == MILZMA_PARKED` -- its decoder state stays in the context; give it a
     /// larger slice (`move_units` carries what it has written: that is its dictionary) and call again with
-    /// `ffi::MILZMA_DECODE_RESUME` and only the parked units.  Nothing is decoded twice.
+    /// `ffi::MILZMA_DECODE_RESUME`, the SAME units in the same order (the parked ones naming their new slices) and the previous
+    /// call's results; only the parked units run.  Nothing is decoded twice.
     ///
     /// # Safety
     /// `d_in` / `d_out` must be device allocations covering every slice the descriptors name, and the caller's own
@@ -125,8 +132,14 @@ impl Context {
         d_out: *mut std::os::raw::c_void,
         hip_stream: *mut std::os::raw::c_void,
         flags: u32,
+        previous: Option<&[ffi::milzma_result]>,
     ) -> error::Result<Vec<ffi::milzma_result>> {
-        let mut results: Vec<ffi::milzma_result> = (0..units.len()).map(|_| std::mem::zeroed()).collect();
+        // (`MILZMA_DECODE_RESUME` reads the previous call's results -- which units are parked -- out of the array it then writes)
+        let mut results: Vec<ffi::milzma_result> = match previous {
+            Some(p) if p.len() == units.len() => p.to_vec(),
+            Some(_) => return Err(error::Error::IoError(std::io::Error::new(std::io::ErrorKind::InvalidInput, "previous results of another batch size"))),
+            None => (0..units.len()).map(|_| std::mem::zeroed()).collect(),
+        };
         let rc = ffi::milzma_decode_units_ex(self.raw, units.as_ptr(), units.len() as u32, d_in, d_out, results.as_mut_ptr(), hip_stream, flags);
         if rc != ffi::MILZMA_OK {
             return Err(infra("milzma_decode_units_ex", ffi::milzma_last_error(self.raw)));

@@ -64,6 +64,9 @@ class XzError(Error):
     kind = XZ_ERROR
 
 
+PATH_STREAMED, PATH_TWO_PART_INPUT, PATH_CLASSIC, PATH_GROUPED = 1, 2, 4, 8   # milzma_last_call_paths
+
+
 class InfraError(Error):
     """Not a reference error: no GPU, HIP failure, bad argument."""
     kind = INFRA_ERROR
@@ -135,7 +138,7 @@ class _COutput(ctypes.Structure):
 
 EXPORTS = [
     "milzma_abi_version", "milzma_create", "milzma_destroy", "milzma_last_error",
-    "milzma_decode_units", "milzma_decode_units_async", "milzma_decode_units_wait", "milzma_decode_units_host", "milzma_last_kernel_ms", "milzma_crc_units",
+    "milzma_decode_units", "milzma_decode_units_async", "milzma_decode_units_wait", "milzma_decode_units_host", "milzma_last_kernel_ms", "milzma_last_call_paths", "milzma_crc_units",
     "milzma_result_message", "milzma_default_options", "milzma_free",
     "milzma_lzma_decompress", "milzma_lzma2_decompress", "milzma_xz_decompress",
     "milzma_lzma_decompress_batch", "milzma_lzma2_decompress_batch", "milzma_xz_decompress_batch",
@@ -188,6 +191,8 @@ def lib():
                                    ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), vp]
     L.milzma_last_kernel_ms.restype = ctypes.c_float
     L.milzma_last_kernel_ms.argtypes = [vp, ctypes.POINTER(u32)]
+    L.milzma_last_call_paths.restype = u32
+    L.milzma_last_call_paths.argtypes = [vp]
     L.milzma_result_message.argtypes = [ctypes.POINTER(Result), u32, ctypes.c_char_p, sz]
     L.milzma_free.argtypes = [vp]
     L.milzma_lzma_decompress.argtypes = [vp, vp, sz, ctypes.POINTER(_COptions), ctypes.POINTER(_COutput)]
@@ -317,6 +322,10 @@ class Context:
         launches = ctypes.c_uint32()
         ms = lib().milzma_last_kernel_ms(self._h, ctypes.byref(launches))
         return results, ms, launches.value
+
+    def last_call_paths(self):
+        """milzma_last_call_paths: PATH_* bits of the way the most recent whole-file batch call took (streamed launch / classic rounds ...)"""
+        return int(lib().milzma_last_call_paths(self._h))
 
     def decode_units_ex(self, units, d_in, d_out, flags, results=None, stream=0):
         """milzma_decode_units_ex: DECODE_GROW parks units that run out of room (Result.status == ST_OUT_FULL, err_a == PARKED);

@@ -47,6 +47,46 @@ struct PinBuf {  // page-locked host staging (hipHostMalloc): PCIe copies run at
 
 thread_local std::string g_create_error;
 
+// ---- environment switches: every MILZMA_* variable the library reads, in ONE table (tests/test_host_abi.py holds README.md against it).
+// "when": create = read once when a context (or the pool / the handle) is made; call = read at every call that could use it, so that a
+// test or an operator can flip it between calls of one process (round 4's knobs were cached in function-local statics: whichever call
+// came first in a process fixed them for good, and a test that set one later ran another path than it thought).
+struct EnvSwitch {
+  const char* name;
+  const char* when;
+  const char* what;
+};
+constexpr EnvSwitch kEnvSwitches[] = {
+    {"MILZMA_KERNEL", "create", "generic: every unit in the generic LDS-model kernel (a test double since round 4)"},
+    {"MILZMA_SPILL", "create", "generic: lc + lp >= 4 in the generic kernel instead of the asm loop's HBM variant"},
+    {"MILZMA_SLICE", "create", "0: never time-slice a launch; 1: always; 2: always, and park every unit at every quantum (tests)"},
+    {"MILZMA_QUANTUM", "create", "output bytes per turn of a time-sliced launch (default 128 KiB)"},
+    {"MILZMA_ORDER", "create", "tuning: stride / shuffle instead of longest-input-first inside a launch"},
+    {"MILZMA_LDS_PAD", "create", "tuning: bytes of unused dynamic LDS per block (occupancy experiments)"},
+    {"MILZMA_POOL_BYTES", "create", "bytes of result buffers kept behind milzma_free (default 8 GiB)"},
+    {"MILZMA_HOST_THREADS", "call", "host threads of the whole-file batch entry points (default min(16, cores))"},
+    {"MILZMA_MULTI_REPLICAS", "create", "testing aid: k contexts per device behind a milzma_multi"},
+    {"MILZMA_TRACE", "create", "phase marks of the whole-file batch calls on stderr"},
+    {"MILZMA_PLAN_BUDGET", "call", "bytes of staging the batch entry points may plan ahead for (default 3/4 of free device memory)"},
+    {"MILZMA_STREAM", "call", "0: no streamed launches"},
+    {"MILZMA_STREAM_MIN", "call", "units[,bytes[,1]] from which a batch is streamed (default 256 units and 256 MiB of output; third field: also ragged batches)"},
+    {"MILZMA_SPAN", "call", "bytes per output span of a streamed launch (default 64 KiB)"},
+    {"MILZMA_PINNED_OUT", "call", "0: pageable result buffers (a host thread copies spans out of a staging buffer)"},
+    {"MILZMA_TWO_PART", "call", "1: .xz batches upload their input in two parts like .lzma batches"},
+    {"MILZMA_ROOTED_STREAM", "call", "0: the one-ingest-point entry brings output home by a copy behind the decode"},
+    {"MILZMA_LANES", "call", "contexts a large whole-file call is spread over (default 2; 3-4 need GPU_MAX_HW_QUEUES >= 2 x lanes + 1)"},
+    {"MILZMA_NO_GROUPS", "call", "a whole-file call is never cut into groups"},
+};
+const char* env_get(const char* name) {
+  bool known = false;
+  for (const EnvSwitch& e : kEnvSwitches) known = known || !strcmp(e.name, name);
+  if (!known) {  // (a switch outside the table is a programming error: loud in every build)
+    fprintf(stderr, "milzma: environment switch %s is not in kEnvSwitches\n", name);
+    abort();
+  }
+  return getenv(name);
+}
+
 }  // namespace
 
 struct UploadTurn {  // whose upload may use the PCIe link now: groups of one call go up in order
@@ -112,6 +152,7 @@ struct milzma_ctx {
                                         // other's kernels whenever one of them drains "its" stream
   float last_ms = 0.f;
   uint32_t last_launches = 0;
+  uint32_t last_paths = 0;              // MILZMA_PATH_* of the most recent whole-file batch call (milzma_last_call_paths)
   // milzma_*_decompress_batch_async: the whole-file batch running on its own host thread until milzma_batch_wait
   std::thread batch_thread;
   bool batch_pending = false;
@@ -158,7 +199,7 @@ hipStream_t work_stream(milzma_ctx* ctx) {
 
 // MILZMA_TRACE=1: wall-clock marks of the whole-file batch phases on stderr (tuning)
 void trace_mark(milzma_ctx* ctx, const char* what) {
-  static const bool on = getenv("MILZMA_TRACE") != nullptr;
+  static const bool on = env_get("MILZMA_TRACE") != nullptr;
   if (!on) return;
   using namespace std::chrono;
   static const steady_clock::time_point t0 = steady_clock::now();
@@ -218,7 +259,7 @@ void pin_release(PinBuf& b) {
 }
 
 unsigned host_threads() {
-  if (const char* e = getenv("MILZMA_HOST_THREADS")) return unsigned(std::max(1, atoi(e)));
+  if (const char* e = env_get("MILZMA_HOST_THREADS")) return unsigned(std::max(1, atoi(e)));
   const unsigned hw = std::thread::hardware_concurrency();
   return std::min(16u, std::max(1u, hw));
 }
@@ -370,14 +411,14 @@ extern "C" int milzma_create(int device, milzma_ctx** out_ctx) {
   }
   auto* ctx = new milzma_ctx();
   ctx->device = device;
-  if (const char* k = getenv("MILZMA_KERNEL")) {
+  if (const char* k = env_get("MILZMA_KERNEL")) {
     ctx->use_fast = strcmp(k, "generic") != 0;
   }
-  if (const char* k = getenv("MILZMA_SPILL")) ctx->fast_spill = strcmp(k, "generic") != 0;
-  if (const char* k = getenv("MILZMA_SLICE")) ctx->slice_mode = !strcmp(k, "2") ? 2 : !strcmp(k, "1") ? 1 : !strcmp(k, "0") ? -1 : 0;
-  if (const char* k = getenv("MILZMA_QUANTUM")) ctx->slice_quantum = std::max<uint32_t>(1u, uint32_t(strtoul(k, nullptr, 0)));
-  if (const char* k = getenv("MILZMA_ORDER")) ctx->order_mode = !strcmp(k, "stride") ? 1 : !strcmp(k, "shuffle") ? 2 : 0;
-  if (const char* k = getenv("MILZMA_LDS_PAD")) {
+  if (const char* k = env_get("MILZMA_SPILL")) ctx->fast_spill = strcmp(k, "generic") != 0;
+  if (const char* k = env_get("MILZMA_SLICE")) ctx->slice_mode = !strcmp(k, "2") ? 2 : !strcmp(k, "1") ? 1 : !strcmp(k, "0") ? -1 : 0;
+  if (const char* k = env_get("MILZMA_QUANTUM")) ctx->slice_quantum = std::max<uint32_t>(1u, uint32_t(strtoul(k, nullptr, 0)));
+  if (const char* k = env_get("MILZMA_ORDER")) ctx->order_mode = !strcmp(k, "stride") ? 1 : !strcmp(k, "shuffle") ? 2 : 0;
+  if (const char* k = env_get("MILZMA_LDS_PAD")) {
     ctx->lds_pad = uint32_t(strtoul(k, nullptr, 0));
   }
   if (!hip_ok(nullptr, hipEventCreate(&ctx->ev0), "hipEventCreate") ||
@@ -427,6 +468,8 @@ extern "C" const char* milzma_last_error(const milzma_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+extern "C" uint32_t milzma_last_call_paths(const milzma_ctx* ctx) { return ctx ? ctx->last_paths : 0u; }
+
 extern "C" float milzma_last_kernel_ms(const milzma_ctx* ctx, uint32_t* launches) {
   if (launches) *launches = ctx ? ctx->last_launches : 0;
   return ctx ? ctx->last_ms : 0.f;
@@ -461,7 +504,7 @@ struct OutPool {
   std::unordered_set<const void*> live;                  // payload pointers handed out and not yet freed
   size_t held = 0, live_bytes = 0, peak_live = 0, limit = size_t(8) << 30;
   OutPool() {
-    if (const char* e = getenv("MILZMA_POOL_BYTES")) limit = size_t(strtoull(e, nullptr, 0));
+    if (const char* e = env_get("MILZMA_POOL_BYTES")) limit = size_t(strtoull(e, nullptr, 0));
   }
   ~OutPool() {
     for (auto& kv : free_by_cap)
@@ -1500,28 +1543,26 @@ struct StreamedSlot {
 // slices: a ragged batch would reserve the largest unit's room for every unit).  MILZMA_STREAM_MIN="units,bytes[,1]": tests send small
 // batches down the path; the third field lifts the one-size condition too (fuzzers: batches of anything).
 void stream_minimum(size_t* units, size_t* bytes, bool* ragged_ok = nullptr) {
-  static size_t mu = 256, mb = size_t(256) << 20;
-  static bool any = false;
-  static const bool init = [] {
-    if (const char* e = getenv("MILZMA_STREAM_MIN")) {
-      char* end = nullptr;
-      mu = size_t(strtoull(e, &end, 0));
-      if (end && *end == ',') {
-        mb = size_t(strtoull(end + 1, &end, 0));
-        if (end && *end == ',') any = strtoull(end + 1, nullptr, 0) != 0;
-      }
+  // (read at every call, not once per process: a test that sets it after the process's first batch call used to be ignored silently --
+  //  the suite's streamed tests then ran the classic path; milzma_last_call_paths is what they assert on now)
+  size_t mu = 256, mb = size_t(256) << 20;
+  bool any = false;
+  if (const char* e = env_get("MILZMA_STREAM_MIN")) {
+    char* end = nullptr;
+    mu = size_t(strtoull(e, &end, 0));
+    if (end && *end == ',') {
+      mb = size_t(strtoull(end + 1, &end, 0));
+      if (end && *end == ',') any = strtoull(end + 1, nullptr, 0) != 0;
     }
-    return true;
-  }();
-  (void)init;
+  }
   *units = mu;
   *bytes = mb;
   if (ragged_ok) *ragged_ok = any;
 }
 
-bool pinned_results_wanted() {
-  static const bool off = getenv("MILZMA_PINNED_OUT") && !strcmp(getenv("MILZMA_PINNED_OUT"), "0");
-  return !off;
+bool pinned_results_wanted() {   // (read at every call: the tests flip it between batches)
+  const char* e = env_get("MILZMA_PINNED_OUT");
+  return !(e && !strcmp(e, "0"));
 }
 
 // Two-part upload for streamed launches.  A decode kernel needs the FIRST bytes of every unit when it starts and the rest only as
@@ -1736,6 +1777,7 @@ namespace {
 
 int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, const milzma_options* opt,
                  bool lzma2, milzma_output* outs) {
+  ctx->last_paths = 0;
   std::vector<milzma_unit> units;
   std::vector<uint32_t> owner;  // unit -> stream
   std::vector<size_t> hdr(n, 0);
@@ -1797,7 +1839,8 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
   } geo;
   StreamedSlot streamed_slot;
   {
-    static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
+    const char* const stream_env = env_get("MILZMA_STREAM");
+    const bool off = stream_env && !strcmp(stream_env, "0");
     size_t max_cap = 0;
     size_t min_units, min_bytes;
     bool ragged_ok = false;
@@ -1811,7 +1854,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     if (all_fast && (ragged_ok || pitch * units.size() <= out_total + out_total / 4) && in_total + pitch * units.size() <= budget &&
         streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
-      if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
+      if (const char* e = env_get("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
       while ((pitch + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
       geo.pitch = pitch;
       geo.span = span;
@@ -1965,6 +2008,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         wr = milzma_decode_units_wait_impl(ctx, res.data());
       }
       trace_mark(ctx, "streamed decode + hand-over: done");
+      ctx->last_paths |= MILZMA_PATH_STREAMED | MILZMA_PATH_TWO_PART_INPUT;
       if (wr != MILZMA_OK) {
         held.drop();
         give_up(active);
@@ -2031,6 +2075,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
         return MILZMA_INFRA_ERROR;
       }
       trace_mark(ctx, "decode: done");
+      ctx->last_paths |= MILZMA_PATH_CLASSIC;
       // What finished travels back packed (an unknown-size stream's slice is a guess several times its output: the link should not
       // carry the slack): the move kernel gathers the finished outputs into a second device buffer, that one comes back in chunks
       // and a stream is handed over as soon as its bytes have arrived.  Where the slices are (nearly) full they go as they are.
@@ -2554,7 +2599,7 @@ size_t check_size(int check) {
 // Bytes of staging (input + output) the batch paths may plan ahead for: MILZMA_PLAN_BUDGET (bytes), else three quarters
 // of the device memory that is free right now.
 size_t plan_budget(milzma_ctx* ctx) {
-  if (const char* e = getenv("MILZMA_PLAN_BUDGET")) return size_t(strtoull(e, nullptr, 0));
+  if (const char* e = env_get("MILZMA_PLAN_BUDGET")) return size_t(strtoull(e, nullptr, 0));
   size_t free_b = 0, total_b = 0;
   if (!ctx || hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return size_t(1) << 32;
   return (free_b / 4 * 3) / std::max(1u, ctx->budget_share) + ctx->in.cap + ctx->out.cap;
@@ -2606,6 +2651,7 @@ bool plan_from_index(const uint8_t* in, size_t n, std::vector<PlannedBlock>* blo
 static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens,
                                           milzma_output* outs) {
   if (!ctx) return MILZMA_INFRA_ERROR;
+  ctx->last_paths = 0;
   // 1. plan: every block the Index of a file names becomes one LZMA2 unit of a single launch
   struct Ref {
     uint32_t file;
@@ -2665,7 +2711,8 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
   bool streamed_done = false, streamed_direct = false;
   std::unordered_map<size_t, std::vector<uint8_t>> longer;   // blocks that came out LONGER than the Index says (their place holds only the Index's size)
   if (nu) {
-    static const bool off = getenv("MILZMA_STREAM") && !strcmp(getenv("MILZMA_STREAM"), "0");
+    const char* const stream_env = env_get("MILZMA_STREAM");
+    const bool off = stream_env && !strcmp(stream_env, "0");
     size_t max_cap = 0;
     for (const milzma_unit& u : units) max_cap = std::max(max_cap, size_t(u.out_cap));
     const size_t pitch = round_up(max_cap, 256);
@@ -2675,7 +2722,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
     if (ctx->use_fast && !off && nu >= min_units && out_total >= min_bytes && (ragged_ok || pitch * nu <= out_total + out_total / 4) &&
         in_total + pitch * nu <= budget && streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
-      if (const char* e = getenv("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
+      if (const char* e = env_get("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
       while ((pitch + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
       geo.pitch = pitch;
       geo.span = span;
@@ -2721,7 +2768,8 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
       // form the .lzma batches use (upload_leads / upload_rest) is there for MILZMA_TWO_PART=1: measured on the 16-core GPU boxes the
       // host's gather (~23 GB/s) is what both forms wait for, and with four blocks per file the second part came too late for the
       // decoders (profiles/r04_batch_api.txt).
-      static const bool two_part = getenv("MILZMA_TWO_PART") && !strcmp(getenv("MILZMA_TWO_PART"), "1");
+      const char* const two_part_env = env_get("MILZMA_TWO_PART");
+      const bool two_part = two_part_env && !strcmp(two_part_env, "1");
       if (!stream_it) (void)hipGetLastError();
       if (!(stream_it && two_part) && !staged_h2d(ctx, ctx->in.p, hin, bounds, fill)) return false;
       if (stream_it) {
@@ -2802,6 +2850,7 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
               wr = milzma_decode_units_wait_impl(ctx, res.data());
             }
             trace_mark(ctx, "streamed decode + placement: done");
+            ctx->last_paths |= MILZMA_PATH_STREAMED | (two_part ? MILZMA_PATH_TWO_PART_INPUT : 0u);
             if (wr != MILZMA_OK) return false;
             streamed_done = true;
             streamed_direct = direct;
@@ -2823,12 +2872,18 @@ static int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const ui
               }
           } else if (milzma_decode_units_wait_impl(ctx, res.data()) != MILZMA_OK) {
             return false;
+          } else {
+            ctx->last_paths |= MILZMA_PATH_CLASSIC;
           }
         } else if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) {
           return false;
+        } else {
+          ctx->last_paths |= MILZMA_PATH_CLASSIC;
         }
       } else if (milzma_decode_units(ctx, units.data(), nu, ctx->in.p, ctx->out.p, res.data(), ws) != MILZMA_OK) {
         return false;
+      } else {
+        ctx->last_paths |= MILZMA_PATH_CLASSIC;
       }
       // (the decode leaves the units and the final results in ctx->units / ctx->results)
       if (streamed_done)   // the output is on the host already: only the blocks' CRC parts are still to come
@@ -3051,7 +3106,7 @@ namespace {
 constexpr uint32_t kChipUnits = 4096, kMinGroupUnits = 512, kMaxGroupUnits = 2048, kMaxLanes = 4;
 
 uint32_t lanes_wanted() {
-  const char* e = getenv("MILZMA_LANES");
+  const char* e = env_get("MILZMA_LANES");
   return e ? std::min<uint32_t>(kMaxLanes, std::max(1, atoi(e))) : 2u;
 }
 
@@ -3060,7 +3115,7 @@ int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const 
                   Call call) {
   std::vector<uint32_t> cut{0};
   const uint32_t want = lanes_wanted();
-  if (ctx && n && ins && in_lens && !getenv("MILZMA_NO_GROUPS")) {
+  if (ctx && n && ins && in_lens && !env_get("MILZMA_NO_GROUPS")) {
     uint64_t total = 0, acc = 0;
     std::vector<uint32_t> u(n);
     for (uint32_t i = 0; i < n; i++) total += (u[i] = units_of(i));
@@ -3126,6 +3181,8 @@ int grouped_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const 
   lane_body(0);
   for (auto& t : th) t.join();
   for (size_t k : not_started) lane_body(k);
+  for (milzma_ctx* lane : ctx->lanes) ctx->last_paths |= lane->last_paths;   // (what any group did, + the cut itself)
+  ctx->last_paths |= MILZMA_PATH_GROUPED;
   int worst = MILZMA_OK;
   for (size_t k = 0; k < nl; k++)
     if (rc[k] != MILZMA_OK) {
@@ -3483,7 +3540,7 @@ extern "C" int milzma_multi_create(uint64_t device_mask, milzma_multi** out) {
     // MILZMA_MULTI_REPLICAS=k (testing aid): k contexts per selected device, each treated as a device of its own -- the partition,
     // the per-device workers and the merge of their results run with several shares on a node that has one GPU.
     int replicas = 1;
-    if (const char* e = getenv("MILZMA_MULTI_REPLICAS")) replicas = std::min(8, std::max(1, atoi(e)));
+    if (const char* e = env_get("MILZMA_MULTI_REPLICAS")) replicas = std::min(8, std::max(1, atoi(e)));
     auto* m = new milzma_multi();
     for (int d = 0; d < 64; d++) {
       if (!((device_mask >> d) & 1)) continue;
@@ -3652,7 +3709,8 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
     //    unit is still being decoded, nothing is left to gather when the kernel ends (equal streams end together: a copy behind the
     //    kernel could overlap nothing).  Otherwise (other classes, no peer access, a promoted LZMA2 unit, MILZMA_ROOTED_STREAM=0): one
     //    peer copy into the root's staging behind the decode, placed by the move kernel below.
-    static const bool stream_back = !(getenv("MILZMA_ROOTED_STREAM") && !strcmp(getenv("MILZMA_ROOTED_STREAM"), "0"));
+    const char* const rooted_env = env_get("MILZMA_ROOTED_STREAM");
+    const bool stream_back = !(rooted_env && !strcmp(rooted_env, "0"));
     std::vector<int> rcode(nd, MILZMA_OK);
     std::vector<uint8_t> wrote_home(nd, 0);
     std::vector<float> t_in(nd, 0.f), t_dec(nd, 0.f), t_out(nd, 0.f);

@@ -849,6 +849,7 @@ def test_time_sliced_launches_match_ordinary_ones(monkeypatch):
     every quantum and taken up again by whichever wave is free (MILZMA_SLICE=2, a 2 KiB quantum) -- and the automatic form, 4100
     units on a chip that holds 4096 waves -- give the oracle's results for good, truncated and damaged .lzma streams of all
     property classes, LZMA2 streams with every chunk kind, and .xz files."""
+    monkeypatch.delenv("MILZMA_KERNEL", raising=False)   # (its own contexts; the module's `ctx` fixture may be alive with MILZMA_KERNEL=generic)
     rng = random.Random(77)
     plains, comps = [], []
     for i in range(40):
@@ -1113,7 +1114,8 @@ def test_streamed_whole_file_batches_match_the_oracle(monkeypatch, pinned):
     streams of every class, unknown sizes (parked and resumed afterwards), truncated and damaged ones, LZMA2 streams and .xz files
     (good, with a lying Index, the 34 malformed ones) must come out exactly as the oracle says."""
     import test_xz_literals as X
-    monkeypatch.setenv("MILZMA_STREAM_MIN", "2,1")
+    monkeypatch.delenv("MILZMA_KERNEL", raising=False)   # (the module's `ctx` fixture may be alive with MILZMA_KERNEL=generic: this test brings its own context)
+    monkeypatch.setenv("MILZMA_STREAM_MIN", "2,1,1")   # (third field: ragged batches too -- the unknown-size members' guessed slices differ by kind)
     monkeypatch.setenv("MILZMA_SPAN", "65536")
     monkeypatch.setenv("MILZMA_PINNED_OUT", pinned)
     rng = random.Random(8)
@@ -1124,12 +1126,16 @@ def test_streamed_whole_file_batches_match_the_oracle(monkeypatch, pinned):
             comps = [W.compress_alone(p, dict_size=1 << 16, known_size=known) for p in plains]
             comps[7] = comps[7][:len(comps[7]) // 2]
             comps[11] = comps[11][:2000] + bytes([comps[11][2000] ^ 0x40]) + comps[11][2001:]
-            for comp, d in zip(comps, c.lzma_batch(comps)):
+            decs = c.lzma_batch(comps)
+            assert c.last_call_paths() & M.PATH_STREAMED, c.last_call_paths()   # (the switch is read per call since round 5: it used to be cached)
+            for comp, d in zip(comps, decs):
                 r = orc.lzma_decompress(comp)
                 assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
         raws = [lzma.compress(W.make_plain("text", 250_000, seed=700 + i) + os.urandom(70_000), format=lzma.FORMAT_RAW,
                               filters=[{"id": lzma.FILTER_LZMA2, "dict_size": 1 << 16}]) for i in range(12)]
-        for comp, d in zip(raws, c.lzma2_batch(raws)):
+        decs = c.lzma2_batch(raws)
+        assert c.last_call_paths() & M.PATH_STREAMED, c.last_call_paths()
+        for comp, d in zip(raws, decs):
             r = orc.lzma2_decompress(comp)
             assert (d.kind, d.msg, d.data, d.in_consumed) == (r.kind, r.msg, r.out, r.in_consumed)
         # .xz: multi-block files of one block size; a file whose Index understates a block; the malformed ones
@@ -1142,7 +1148,9 @@ def test_streamed_whole_file_batches_match_the_oracle(monkeypatch, pinned):
             idx = X.index([(bl[0][1], bl[0][2]), (bl[1][1], bl[1][2] - lie), (bl[2][1], bl[2][2])])
             xzs.append(X.xz_file(check=4, blocks=bl, idx=idx))
         xzs += [data for _name, (data, _k, _m) in sorted(X.CASES.items())]
-        for comp, d in zip(xzs, c.xz_batch(xzs)):
+        decs = c.xz_batch(xzs)
+        assert c.last_call_paths() & M.PATH_STREAMED, c.last_call_paths()
+        for comp, d in zip(xzs, decs):
             r = orc.xz_decompress(comp)
             assert (d.kind, d.msg, d.data) == (r.kind, r.msg, r.out)
     finally:

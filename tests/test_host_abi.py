@@ -208,3 +208,19 @@ def test_asm_loops_sit_in_the_code_object_untouched():
         else:
             assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
         assert m["vgpr_count"] <= 128, (name, m)     # four waves per SIMD
+
+
+def test_every_environment_switch_is_in_the_table_and_in_the_readme():
+    """lzma_rs_amd/csrc/host.cpp reads its MILZMA_* switches through env_get(), which aborts on a name outside kEnvSwitches: the table is
+    the whole list.  README.md must describe every one of them (and the code must not read the environment behind the table's back)."""
+    src = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "host.cpp")).read()
+    table = re.search(r"constexpr EnvSwitch kEnvSwitches\[\] = \{(.*?)\n\};", src, flags=re.S).group(1)
+    names = re.findall(r'\{"(MILZMA_[A-Z_0-9]+)", "(create|call)"', table)
+    assert len(names) >= 19 and len({n for n, _ in names}) == len(names)
+    used = set(re.findall(r'env_get\("(MILZMA_[A-Z_0-9]+)"\)', src))
+    assert used == {n for n, _ in names}, used ^ {n for n, _ in names}
+    raw = [m for m in re.findall(r'(?<!env_)getenv\("(MILZMA_[A-Z_0-9]+)"\)', src)]
+    assert not raw, "read behind the table's back: %r" % raw
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for n, _ in names:
+        assert "`" + n in readme, n + " is not described in README.md"

@@ -32,16 +32,18 @@ def main():
             newest[name] = path
     for path in sorted(newest.values()):
         per = defaultdict(lambda: defaultdict(float))
+        ms_of = {}
         for r in csv.DictReader(open(path)):
             if key not in r["Kernel_Name"]:
                 continue
             per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
-            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            ms_of[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         if not per:
             continue
         if first_only:
             first = min(per, key=lambda d: int(d))
             per = {first: per[first]}
+        dur.extend(ms_of[d] for d in per)
         name = path[len(src):].strip("/").split("/")[0]
         passes[name] = len(per)
         for c in sorted({c for d in per.values() for c in d}):
