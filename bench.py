@@ -275,6 +275,9 @@ def cpu_baseline(size, kind, dict_size, cores):
         dt_xz = time.time() - t0
     assert got == n_all * size
     return {"value": round(many, 4), "unit": "GB/s decompressed", "cores": cores, "kind": "port",
+            "host": {"logical_cpus": os.cpu_count(), "usable_cpus": cores,
+                     "note": "the box exposes %s hardware threads; the container's cgroup quota grants %d of them, and that is what every CPU "
+                             "figure here ran on -- a whole host of this class has an order of magnitude more" % (os.cpu_count(), cores)},
             "sample": "%d x %d B %s streams, dict %d, oracle/lzma_oracle.c (C restatement of the reference; no Rust "
                       "toolchain to build the crate), one stream per thread, median of 3 runs (%.2f s each)"
                       % (n_all, size, kind, dict_size, t_many),

@@ -74,6 +74,7 @@ constexpr EnvSwitch kEnvSwitches[] = {
     {"MILZMA_PINNED_OUT", "call", "0: pageable result buffers (a host thread copies spans out of a staging buffer)"},
     {"MILZMA_TWO_PART", "call", "1: .xz batches upload their input in two parts like .lzma batches"},
     {"MILZMA_ROOTED_STREAM", "call", "0: the one-ingest-point entry brings output home by a copy behind the decode"},
+    {"MILZMA_ROOTED_PEER", "call", "0: the one-ingest-point entry treats peer access to the root as denied (tests: the fallback when a device cannot reach the root's memory)"},
     {"MILZMA_LANES", "call", "contexts a large whole-file call is spread over (default 2; 3-4 need GPU_MAX_HW_QUEUES >= 2 x lanes + 1)"},
     {"MILZMA_NO_GROUPS", "call", "a whole-file call is never cut into groups"},
 };
@@ -3746,6 +3747,7 @@ extern "C" int milzma_multi_decode_units_rooted(milzma_multi* m, uint32_t root, 
             direct = direct && classify(c, u) == kFast;
             max_cap = std::max<uint64_t>(max_cap, u.out_cap);
           }
+          if (const char* peer_env = env_get("MILZMA_ROOTED_PEER"); peer_env && !strcmp(peer_env, "0")) direct = false;
           if (direct && c->device != rc->device) {
             int can = 0;
             direct = hipDeviceCanAccessPeer(&can, c->device, rc->device) == hipSuccess && can != 0;

@@ -751,16 +751,24 @@ def test_multi_device_entry_points_match_single_device(ctx, monkeypatch, shares)
         assert all(ms > 0 for ms in m.kernel_ms())
         # one ingest point: everything resident on device index `root`; the other devices' shares are packed, cross device to device
         # (hipMemcpyPeer), are decoded there and come back into the slices the descriptors name
-        for root in range(shares):
-            d_out2 = torch.zeros(out_off + 512, dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()     # (the library's own streams do not order themselves behind torch's)
-            r4, (t_in, t_dec, t_out) = m.decode_units_rooted(root, arr, d_in.data_ptr(), d_out2.data_ptr())
-            got = d_out2.cpu().numpy().tobytes()
-            for u, a, b in zip(units, r4, r2):
-                assert (a.status, a.out_len, a.out_flushed, a.in_consumed, a.err_a, a.err_b) == (b.status, b.out_len, b.out_flushed, b.in_consumed, b.err_a, b.err_b)
-                n = min(a.out_len, u.out_cap)
-                assert got[u.out_off:u.out_off + n] == bytes(o2[u.out_off:u.out_off + n])
-            assert t_dec > 0 and (shares == 1 or (t_in > 0 and t_out > 0))
+        # ... by every way back the entry has: the decoding waves' own stores into the root's slices (default), one copy behind the decode
+        # (MILZMA_ROOTED_STREAM=0), and the same copy because peer access to the root is denied (MILZMA_ROOTED_PEER=0: what a device that
+        # cannot reach the root's memory does) -- the switches are read per call
+        for way in ({}, {"MILZMA_ROOTED_STREAM": "0"}, {"MILZMA_ROOTED_PEER": "0"}):
+            for k, v in way.items():
+                monkeypatch.setenv(k, v)
+            for root in range(shares):
+                d_out2 = torch.zeros(out_off + 512, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()     # (the library's own streams do not order themselves behind torch's)
+                r4, (t_in, t_dec, t_out) = m.decode_units_rooted(root, arr, d_in.data_ptr(), d_out2.data_ptr())
+                got = d_out2.cpu().numpy().tobytes()
+                for u, a, b in zip(units, r4, r2):
+                    assert (a.status, a.out_len, a.out_flushed, a.in_consumed, a.err_a, a.err_b) == (b.status, b.out_len, b.out_flushed, b.in_consumed, b.err_a, b.err_b)
+                    n = min(a.out_len, u.out_cap)
+                    assert got[u.out_off:u.out_off + n] == bytes(o2[u.out_off:u.out_off + n]), (way, root)
+                assert t_dec > 0 and (shares == 1 or (t_in > 0 and t_out > 0))
+            for k in way:
+                monkeypatch.delenv(k)
         with pytest.raises(M.InfraError):
             m.decode_units_rooted(shares, arr, d_in.data_ptr(), d_out.data_ptr())     # no such root
         # descriptor checks as in the single-device host call

@@ -202,11 +202,17 @@ def test_asm_loops_sit_in_the_code_object_untouched():
     rep, problems = C.check(os.path.join(ROOT, "lzma_rs_amd", "libmilzma.so"))
     assert not problems, problems
     assert len(rep["loops"]) == 8
+    # A spill budget per kernel, so that the figures cannot double unnoticed again (373 -> 588 VGPR spills in one round).
+    # The time-sliced kernel's spills sit around its park / unpark code (21.5 KB of state per unit: parking IS a round trip through
+    # memory) and run once per TURN -- about 900 scratch instructions against the ~7 million instructions of a 128 KiB turn; measured:
+    # 4096 streams through the sliced kernel take the ordinary kernel's time, parked at every quantum +0.5 % (profiles/r05_sliced_and_streamed.txt).
     for name, m in rep["kernels"].items():
         if "sliced" in name:
-            assert m["private_segment_fixed_size"] <= 2048, (name, m)
+            assert m["private_segment_fixed_size"] <= 1600 and m["vgpr_spill_count"] <= 650, (name, m)
+            assert m["scratch_instructions_outside_the_loops"] <= 1000, (name, m)
         else:
             assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
+            assert m["scratch_instructions_outside_the_loops"] <= 8, (name, m)
         assert m["vgpr_count"] <= 128, (name, m)     # four waves per SIMD
 
 
