@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MILZMA_ABI_VERSION 3
+#define MILZMA_ABI_VERSION 4
 
 /* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
 enum {

@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_float, c_int, c_void};
 
-pub const MILZMA_ABI_VERSION: u32 = 3;
+pub const MILZMA_ABI_VERSION: u32 = 4;
 
 // error kinds: error::Error variants (src/error.rs:8-17)
 pub const MILZMA_OK: c_int = 0;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libmilzma.so does not export " + name
     assert set(M.EXPORTS) == declared
-    assert L.milzma_abi_version() == 3
+    assert L.milzma_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
