@@ -217,9 +217,10 @@ def test_asm_loops_sit_in_the_code_object_untouched():
 
 
 def test_every_environment_switch_is_in_the_table_and_in_the_readme():
-    """lzma_rs_amd/csrc/host.cpp reads its MILZMA_* switches through env_get(), which aborts on a name outside kEnvSwitches: the table is
+    """lzma_rs_amd/csrc/host*.cpp read their MILZMA_* switches through env_get(), which aborts on a name outside kEnvSwitches: the table is
     the whole list.  README.md must describe every one of them (and the code must not read the environment behind the table's back)."""
-    src = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "host.cpp")).read()
+    import glob
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "lzma_rs_amd", "csrc", "host*.cpp")) + [os.path.join(ROOT, "lzma_rs_amd", "csrc", "host_internal.h")]))
     table = re.search(r"constexpr EnvSwitch kEnvSwitches\[\] = \{(.*?)\n\};", src, flags=re.S).group(1)
     names = re.findall(r'\{"(MILZMA_[A-Z_0-9]+)", "(create|call)"', table)
     assert len(names) >= 19 and len({n for n, _ in names}) == len(names)
