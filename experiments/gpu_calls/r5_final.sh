@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5, final kernel (alignment pinned): evidence passes (r5_evidence.sh), the whole GPU suite, the default bench line
+cd $GRAFT_REPO_ROOT
+bash experiments/gpu_calls/r5_evidence.sh
+export TMPDIR=/tmp
+export MILZMA_BENCH_CACHE=/tmp/milzma_bench_cache
+O=gpurun_out/r5_final; rm -rf $O; mkdir -p $O
+cp gpurun_out/r5_ev/r05_pmc_*.json profiles/ 2>/dev/null
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 | tee $O/suite.txt
+timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; tail -c 300 $O/bench_default.json; tail -2 $O/bench_default.err

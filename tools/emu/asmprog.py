@@ -86,6 +86,8 @@ class Program:
             s = ln.strip()
             if not s:
                 continue
+            if s.startswith("."):      # an assembler directive (.p2align in front of a branch target): nothing to execute
+                continue
             if s.endswith(":"):
                 name = s[:-1]
                 self.labels[name] = len(self.text)

@@ -171,9 +171,19 @@ SYM_M0 = SYM_M0 and "wb" not in SSHADOW and not ALIGNLAZY and not LENDEFER   # (
 #                                                                              update that reads it, live across an s_set_gpr_idx_on)
 S1 = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_S1", ""))))
 FORMA2 = os.environ.get("MILZMA_GEN_FORMA2", "0") == "1"
+#   PRESYMV: the update constant of an immediately updated tree level (K = 2048 for a 0 bit, 31 for a 1 bit) from the symbol's new low bit on the
+#       vector ALU (v_and + v_mad, queued with the update) instead of s_cselect_b32 behind the decision: one scalar instruction less per such level
+PRESYMV = os.environ.get("MILZMA_GEN_PRESYMV", "0") == "1"
+#   ALIGN_STUBS: log2 of the alignment of out-of-line branch targets that are only ever reached by a taken branch (the normalisation stubs: 0.74 taken
+#       branches per byte go in and out of them) -- the padding in front of such a label is never executed
+ALIGN_STUBS = int(os.environ.get("MILZMA_GEN_ALIGN_STUBS", "0"))
 K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
-ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "0"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
+# Where the loop's code falls in the 32-byte instruction fetch lines is worth +-1.2 % (round 5, profiles/r05_kernel_ab.txt section 4: the loop 64-byte
+# aligned + 0 / 2 dwords 224.5 ms, + 4 / 6 dwords 222.4, + 8 / 10 225.0, + 12 / 14 223.0: period 32 bytes).  Left to wherever the compiler's code in front
+# of the asm statement ends, the phase changed with every edit of the C++ around the loop; pinned: 32-byte aligned + 6 dwords (221.8 ms; + 4: 222.0, + 5: 222.5, + 7: 223.4; unpinned as it happened to fall: 221.8).
+ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "5"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
+ALIGN_PAD = int(os.environ.get("MILZMA_GEN_ALIGN_PAD", "6"))   # ... + this many 4-byte s_nop behind the alignment: the phase of the loop's code in its fetch lines
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "6"))   # (round 5: 6 instead of 4: -0.4 %, with and without SYM_M0)
@@ -344,7 +354,7 @@ class Gen:
             # a queued instruction must be emitted before something it reads is overwritten
             if S["sym"] == "m0" and (op == "s_set_gpr_idx_on" or (ops[1] == "m0" and op == "s_mov_b32")) and any(x[1] for x in self.q):
                 raise AssertionError("m0 (the symbol) is overwritten while a deferred update still reads it: " + out)
-            if ops[1] == S["sym"] and any(x[1] for x in self.q):
+            if ops[1] == S["sym"] and not op.startswith(("s_cmp", "s_bitcmp")) and any(x[1] for x in self.q):   # (compares only read it)
                 raise AssertionError("sym is overwritten while a deferred update still reads it: " + out)
             if ops[1] == "vcc" and op.startswith("v_") and any(x[2] for x in self.q):
                 raise AssertionError("vcc is overwritten while a deferred update still reads it: " + out)
@@ -480,6 +490,8 @@ class Gen:
             with self.at(role="book"):
                 self.e("s_branch " + self.L(to))
         with Gen._Into(self, self.stubs), self.at(role="normstub"):
+            if ALIGN_STUBS:
+                self.cur.append(".p2align %d" % ALIGN_STUBS)
             self.lab(k)
             if not EOFWRAP:
                 self.e("s_cmp_eq_u32 {off}, {lim}")
@@ -604,11 +616,24 @@ class Gen:
     @role("update")
     def pre_sym(self):
         """scalar part of the update of a tree decision; call while SCC = (bit == 0)"""
-        self.e("s_cselect_b32 {sk}, 0x800, 31")
+        if not PRESYMV:
+            self.e("s_cselect_b32 {sk}, 0x800, 31")
 
     @role("update")
     def post_sym(self, T, half=None, defer=True):
         """probability update of a tree decision (the symbol's new low bit is 1 if the bit was 0)"""
+        if PRESYMV and half is None and defer and "single" in DEFER:
+            # (the symbol's low bit is 1 for a 0 bit: K = 31 + 2017 * (sym & 1); read before the next decision extends the symbol)
+            self.defer("v_and_b32 {DVX}, 1, {sym}", reads_sym=True)
+            self.defer("v_mad_u32_u24 {DVX}, {DVX}, {c2017}, 31")
+            self.defer("v_mad_u32_u24 {DVT}, {T}, 31, {DVX}", T=T)
+            self.defer("v_lshrrev_b32 {DVT}, 5, {DVT}")
+            self.defer("v_cndmask_b32 {T}, {T}, {DVT}, vcc", reads_vcc=True, T=T)
+            return
+        if PRESYMV:
+            self.e("s_and_b32 {sk}, {sym}, 1")
+            self.e("s_mul_i32 {sk}, {sk}, 2017")
+            self.e("s_add_u32 {sk}, {sk}, 31")
         if half is None:
             if defer and "single" in DEFER:      # (sk stays valid: the next decision's pre_sym comes after its shadow)
                 self.defer("v_mad_u32_u24 {DVT}, {T}, 31, {sk}", T=T)
@@ -2020,6 +2045,8 @@ def main():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
         if ALIGN:
             out.append('  ".p2align %d\\n\\t" \\' % ALIGN)
+            for _ in range(ALIGN_PAD):
+                out.append('  "s_nop 0\\n\\t" \\')
         for l in lines:
             out.append('  "%s\\n\\t" \\' % l.strip())
         out.append('  ""')
