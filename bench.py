@@ -549,7 +549,9 @@ def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
             "roofline": {"bound": "hbm", "achieved": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                          "algorithmic_bytes_per_launch": comp_total + out_total,
-                         "traffic": pmc_traffic("unknown_size", kernel_source_hash())[0] if (n, size) == (cfg["streams"], cfg["size"]) else None}}
+                         "traffic": pmc_traffic("unknown_size", kernel_source_hash())[0] if (n, size) == (cfg["streams"], cfg["size"]) else None},
+            # (the instruction mix of configs[1]: the same streams -- a size-less header changes no symbol, the end marker adds one per stream)
+            "roofline_issue": issue_roofline("lzma64k", "text", out_total, k_ms, kernel_source_hash(), units=n) if size == cfg["size"] else None}
 
 
 def run_inproc(args):

@@ -196,6 +196,34 @@ def test_emulated_loop_yields_at_quanta(loops, lc, lp, pb):
     assert most > 1000                           # quantum 1 on random data: a yield at (nearly) every symbol
 
 
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # the LP0, GEN, PB4 and HBM variants of the loop
+def test_emulated_loop_fed_in_views(loops, lc, lp, pb):
+    """MILZMA_DECODE_FEED at the level of the loop (round 5): the input arrives in views of arbitrary lengths (down to a byte more than the
+    one before).  With the FEED bit the loop leaves at the first symbol top with fewer than FEED_MARGIN bytes of its view left -- never in
+    the middle of a symbol --, is re-entered on the longer view, and runs the whole payload last without the bit: bytes, verdict and reader
+    position are the oracle's, for good streams of known and unknown size and for a truncated one."""
+    import gen_fast_loop as G
+    loop = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    rng = random.Random(lc * 100 + lp * 10 + pb)
+    for kind, known, size in (("text", True, 90000), ("text", False, 40000), ("random", True, 9000), ("repeat", False, 50000)):
+        plain = W.make_plain(kind, size, seed=77 + size)
+        comp = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=known)
+        pay = comp[13:]
+        cuts = sorted(set(rng.randrange(1, len(pay)) for _ in range(14)) | set(range(200, min(len(pay), 232))))   # (32 views one byte apart)
+        r = loop.decode_raw(pay, lc, lp, pb, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300, feed_views=cuts)
+        ref = orc.lzma_decompress(comp)
+        assert r["status"] == "OK" and r["out"] == plain and r["in_consumed"] + 13 == ref.in_consumed, (kind, known)
+        assert len(r["feeds"]) >= len(cuts) - 33     # (a view a byte longer than a stop inside the margin stops again at once: fine, and exercised)
+        for view, pos in r["feeds"]:
+            assert 0 <= view - pos < G.FEED_MARGIN
+    plain = W.make_plain("text", 60000, seed=9)
+    comp = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=True)
+    cut = comp[:len(comp) // 2]
+    r = loop.decode_raw(cut[13:], lc, lp, pb, 1 << 16, len(plain), out_cap=len(plain) + 300, feed_views=[50, 4000, len(cut) - 13 - 7])
+    ref = orc.lzma_decompress(cut)
+    assert r["status"] == "INPUT_EOF" and r["in_consumed"] + 13 == ref.in_consumed and r["out"][:len(ref.out)] == ref.out
+
+
 def test_emulated_hbm_variant_lclp_above_four():
     """The HBM variant of the loop (lc + lp > 4: the 2^(lc+lp) literal rows in a slab in memory, eight register rows and eight LDS
     rows as direct-mapped caches over it, tags in two VGPRs' lanes): streams with real match structure for every kind of property set

@@ -402,23 +402,31 @@ class AsmLoop:
             pos += hdr + packed
 
     # ---- the kernel around the loop (decode_fast_asm.hip.h), raw LZMA units only ------------------------------
-    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None):
+    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None, feed_views=None):
         """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode).
         quantum: output bytes after which the loop yields at the next symbol top (the time-sliced launches); the front end then does
-        what the kernel's resume does (re-seeks the reader from its position, has the per-lane tables rebuilt) and re-enters."""
+        what the kernel's resume does (re-seeks the reader from its position, has the per-lane tables rebuilt) and re-enters.
+        feed_views: ascending prefix lengths of `payload` -- the input arrives in VIEWS (MILZMA_DECODE_FEED): the loop runs with the FEED bit
+        on the first feed_views[0] bytes, leaves with NEED_INPUT at a symbol top near the view's end, and is re-entered on the next, longer
+        view (the reader re-seeked at its position, as the kernel's resume does); the whole payload comes last, without the bit.
+        The result then carries `feeds` = [(view length, reader position at the stop), ...]."""
         G = self.G
         if out_cap is None:
             out_cap = unpacked_size if unpacked_size is not None else len(payload) * 64 + 4096
+        views = list(feed_views or []) + [len(payload)]
+        full_payload = payload
+        payload = full_payload[:views[0]]
+        feeds = []
         in_len = len(payload)
         IN0 = 64  # (bytes 0..3 of the emulated memory: the "last block has started" flag, set)
-        in_span = (in_len + 63 + 128) & ~63
+        in_span = (len(full_payload) + 63 + 128) & ~63
         OUT0 = IN0 + in_span + 64
         SLAB0 = (OUT0 + out_cap + 512 + 255) & ~255
         slab_bytes = (0x600 << (lc + lp)) if self.hbm else 0
         mem = np.zeros(SLAB0 + slab_bytes + 64, dtype=np.uint8)
         if slab_bytes:     # every probability 0x400 (the host memsets the slab before the launch)
             mem[SLAB0:SLAB0 + slab_bytes].view(np.uint16)[:] = 0x400
-        mem[IN0:IN0 + in_len] = np.frombuffer(bytes(payload), dtype=np.uint8)
+        mem[IN0:IN0 + len(full_payload)] = np.frombuffer(bytes(full_payload), dtype=np.uint8)
         mem[0] = 1
         if "flagptr" in self.regmap:
             i = self._sidx("flagptr")
@@ -432,7 +440,7 @@ class AsmLoop:
         def window(wpos):
             w = np.zeros(64, dtype=np.uint32)
             for l in range(64):
-                if wpos + l < in_len:
+                if 0 <= wpos + l < in_len:
                     w[l] = payload[wpos + l]
             return w
 
@@ -475,7 +483,7 @@ class AsmLoop:
         S("safe_len", out_lim - 273 if out_lim >= 273 else 0)
         S("dict_size", dict_size)
         S("lc", lc)
-        S("lc8", 8 - lc)
+        S("lc8", (8 - lc) | ((1 << G.FEED_BIT) if len(views) > 1 else 0))
         S("lpmask", (1 << lp) - 1)
         S("pbmask", (1 << pb) - 1)
         S("ldsbase", 0)
@@ -492,6 +500,23 @@ class AsmLoop:
             executed += n
             ex = self.sget("exitcode") & 0xFF      # (bit 8: "re-seek before reading on" -- positions are right either way)
             S("exitcode", ex)
+            if ex == G.EXIT["NEED_INPUT"]:
+                # MILZMA_DECODE_FEED: parked at a symbol top near the end of the view; the next view is longer (here: of the same buffer)
+                v = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF
+                feeds.append((in_len, v))
+                assert len(views) > 1 and in_len - v < G.FEED_MARGIN, (in_len, v)
+                views.pop(0)
+                payload = full_payload[:views[0]]
+                in_len = len(payload)
+                self.set_rsrc("in_rsrc", IN0, in_len)
+                S("lc8", (8 - lc) | ((1 << G.FEED_BIT) if len(views) > 1 else 0))
+                S("wbase", v & ~63)
+                S("off", v & 63)
+                S("lim", (v & 63) + (in_len - v))
+                self.vset(self._vidx("winb"), window(v & ~63))
+                self.vset(self._vidx("winb_next"), window((v & ~63) + 64))
+                S("tbl_ready", 0)
+                continue
             if ex == G.EXIT["QUANTUM"]:
                 # resume: seek(vpos(), rem()) -- aligned windows, off = lane -- and tables rebuilt on entry
                 yields += 1
@@ -547,7 +572,7 @@ class AsmLoop:
             in_consumed = (in_consumed - 1) & 0xFFFFFFFF
             assert in_consumed == in_len, (in_consumed, in_len)
         return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,
-                    executed=executed, yields=yields)
+                    executed=executed, yields=yields, feeds=feeds)
 
     # ---- executed-instruction statistics ------------------------------------------------------------------
     def counts(self):

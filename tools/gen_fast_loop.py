@@ -239,7 +239,13 @@ set_layout()
 CLOBBER_S = sorted((set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}) - {"m0"}, key=lambda r: int(r[1:]))   # (m0 cannot be listed: the compiler sets it wherever it needs it)  # (+ DM, the refill return address)
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
-            MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9, QUANTUM=10)
+            MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9, QUANTUM=10, NEED_INPUT=11)
+# FEED (round 5, MILZMA_DECODE_FEED): bit 8 of the lc8 operand (the shift that uses it takes the low five bits) says that the input the reader
+# sees is a VIEW that will be continued: the loop then leaves at the first symbol top with fewer than FEED_MARGIN bytes of the view left
+# (exit NEED_INPUT: nothing of the next symbol looked at; the reference's Stream keeps 20 bytes back for the same reason, stream.rs) instead of
+# running a symbol into the end of the view.  Costs the ordinary loop two scalar instructions per window refill (set_guards).
+FEED_BIT = 8
+FEED_MARGIN = 32
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
                "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc", "tbl_ready"]
@@ -877,7 +883,10 @@ class Gen:
         # gtop = 0 (every symbol looks closer) while the reader may be at EOF before the symbol ends.  (lim is a u32 of up to 4 GiB:
         # no signed compares on it)
         if EOFWRAP:
-            e("s_cmp_lg_u32 {lim}, -1")                     # -1: the reader IS at EOF
+            # every symbol looks closer once the reader is at EOF (lim = -1) -- with FEED: from the view's last window on (lim = 0, -1)
+            e("s_bfe_u32 {gdist}, {lc8}, 0x%x" % ((1 << 16) | FEED_BIT))    # (gdist: set below)
+            e("s_add_u32 {t}, {lim}, 1", t=t)
+            e("s_cmp_gt_u32 {t}, {gdist}", t=t)
         elif OFFBIAS:
             e("s_add_u32 {t}, {lim}, 64", t=t)
             e("s_cmpk_gt_u32 {t}, 63", t=t)
@@ -1223,6 +1232,17 @@ class Gen:
             e("s_cbranch_scc1 " + L("Xdone_size"))
             e("s_cmp_gt_u32 {len}, {safe_len}")           # from here on every match looks closer
             e("s_cselect_b32 {gdist}, 0, {gdist}")
+            if EOFWRAP:   # FEED: fewer than FEED_MARGIN bytes of the view left (lim = 0: the last window, -off of them left; -1: none)
+                e("s_bitcmp1_b32 {lc8}, %d" % FEED_BIT)
+                e("s_cbranch_scc0 " + L("Onofeed" + tag))
+                e("s_add_u32 {t0}, {lim}, 1")
+                e("s_cmp_gt_u32 {t0}, 1")
+                e("s_cbranch_scc1 " + L("Onofeed" + tag))
+                e("s_cmp_eq_u32 {lim}, -1")
+                e("s_cbranch_scc1 " + L("Xneed_input"))
+                e("s_cmp_gt_i32 {off}, %d" % -FEED_MARGIN)
+                e("s_cbranch_scc1 " + L("Xneed_input"))
+                lab("Onofeed" + tag)
             e("s_cmp_eq_u32 {off}, {lim}")                    # reader at EOF: the stream may be finished
             e("s_cbranch_scc0 " + L("top2" + tag))
             lab("Ofin_check" + tag)                           # unknown size: finished when the reader is at EOF
@@ -1990,7 +2010,8 @@ class Gen:
             for name, code in [("Xdone_size", "DONE_SIZE"), ("Xdone_fin", "DONE_FIN"), ("Xeof", "INPUT_EOF"),
                                ("Xmarker", "MARKER"), ("Xlimit", "LIMIT"), ("Xlz_slow", "LZ_SLOW"),
                                ("Xmatch_dist_dict", "MATCH_DIST_DICT"), ("Xmatch_dist_out", "MATCH_DIST_OUT"),
-                               ("Xlz_dist_dict", "LZ_DIST_DICT"), ("Xlz_dist_out", "LZ_DIST_OUT"), ("Xquantum", "QUANTUM")]:
+                               ("Xlz_dist_dict", "LZ_DIST_DICT"), ("Xlz_dist_out", "LZ_DIST_OUT"), ("Xquantum", "QUANTUM"),
+                               ("Xneed_input", "NEED_INPUT")]:
                 lab(name)
                 self.exit_with(code)
 
