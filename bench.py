@@ -531,6 +531,36 @@ def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
     torch.cuda.synchronize(dev)
     wrong_s = time.perf_counter() - t0
     bad2 = verify(units, res, d_out)
+    del d_out
+    torch.cuda.empty_cache()
+
+    # 3. fed input (MILZMA_DECODE_FEED): the same streams arriving in four pieces -- every unit parks at the end of its view three times
+    #    and resumes on a longer view of the same buffer; nothing is decoded twice, the sum of the four kernels is the figure
+    units, out_bytes, _ = layout(lambda u: (max(1 << 16, 6 * u.in_len) + 255) & ~255)
+    d_out = torch.zeros(out_bytes + 512, dtype=torch.uint8, device=dev)
+    whole = [(units[k].in_off, units[k].in_len) for k in range(n)]
+    used = [0] * n
+    live = list(range(n))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    res, ms_feed, feed_parks, feed_ms = None, 0.0, 0, []
+    for step, frac in enumerate((0.25, 0.5, 0.75, 1.0)):
+        for k in live:
+            end = whole[k][1] if frac == 1.0 else int(whole[k][1] * frac)
+            units[k].in_off, units[k].in_len = whole[k][0] + used[k], end - used[k]
+            units[k].kind = M.KIND_RAW_LZMA | (M.KIND_LAST_VIEW if frac == 1.0 else 0)
+        res, ms, _ = ctx.decode_units_ex(units, d_in.data_ptr(), d_out.data_ptr(), M.DECODE_FEED | (M.DECODE_RESUME if step else 0),
+                                         results=res, stream=stream)
+        feed_ms.append(round(ms, 3))
+        live = [k for k in live if res[k].err_a == M.PARKED and res[k].status in (M.ST_NEED_INPUT, M.ST_OUT_FULL)]
+        for k in live:
+            used[k] += res[k].in_consumed
+        feed_parks += len(live)
+    torch.cuda.synchronize(dev)
+    feed_s = time.perf_counter() - t0
+    for k in range(n):
+        units[k].kind = M.KIND_RAW_LZMA
+    bad3 = verify(units, res, d_out) + len(live)
     del d_out, d_in
     torch.cuda.empty_cache()
     out_total = n * size
@@ -546,6 +576,11 @@ def run_unknown_size(args, M, torch, dev, ctx, procs, steps, warmup):
                                           % n,
                                   "value": round(out_total / wrong_s / 1e9, 4), "unit": "GB/s", "seconds": round(wrong_s, 4),
                                   "kernel_ms_sum": round(ms_all, 3), "rounds": rounds, "units_parked": parked_total, "bit_exact": bad2 == 0},
+            "fed_in_four_views": {"what": "MILZMA_DECODE_FEED: every stream arrives in four pieces (25 / 50 / 75 / 100 %% of its payload): %d units "
+                                          "park at the end of their view three times and resume on a longer one; wall time of the four calls "
+                                          "(with this script's per-unit Python between them), nothing decoded twice" % n,
+                                  "value": round(out_total / feed_s / 1e9, 4), "unit": "GB/s", "seconds": round(feed_s, 4),
+                                  "kernel_ms": feed_ms, "kernel_ms_sum": round(sum(feed_ms), 3), "units_parked": feed_parks, "bit_exact": bad3 == 0},
             "roofline": {"bound": "hbm", "achieved": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round((comp_total + out_total) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                          "algorithmic_bytes_per_launch": comp_total + out_total,

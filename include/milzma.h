@@ -45,6 +45,7 @@ enum {
 /* unit kinds */
 #define MILZMA_KIND_RAW_LZMA 0u /* LzmaDecoder::decompress: input starts at the range coder's first byte */
 #define MILZMA_KIND_LZMA2 1u    /* Lzma2Decoder::decompress: input starts at an LZMA2 status byte          */
+#define MILZMA_KIND_LAST_VIEW 0x80u /* or-ed into `kind` in a MILZMA_DECODE_FEED call: this unit's view ends where its stream ends */
 
 #define MILZMA_SIZE_UNKNOWN UINT64_MAX /* unpacked_size: Option::None => end-of-stream marker mode */
 #define MILZMA_NO_LIMIT UINT64_MAX     /* memlimit: Option::None                                    */
@@ -94,8 +95,11 @@ enum {
   MILZMA_ST_NEED_LCLP = 33,  /* unit needs a literal table for lc+lp = {a} larger than its launch class */
   MILZMA_ST_BAD_UNIT = 34,   /* descriptor rejected (slice > MILZMA_MAX_UNIT_BYTES, lc>8, lp>4, pb>4)   */
   MILZMA_ST_NEED_GENERIC = 35, /* props outside the fast kernel's specialisation: rerun in the generic one */
-  MILZMA_ST_NEED_RERUN = 36   /* internal to the whole-file calls' streamed launches (their input goes up in two parts): a unit read
+  MILZMA_ST_NEED_RERUN = 36,  /* internal to the whole-file calls' streamed launches (their input goes up in two parts): a unit read
                                  beyond the part that was in place: its output is void, it is decoded again                      */
+  MILZMA_ST_NEED_INPUT = 37   /* MILZMA_DECODE_FEED: the unit stopped within 32 bytes of the end of its input VIEW (err_a ==
+                                 MILZMA_PARKED, always); in_consumed = bytes of the view it has used.  Resume it with a view that
+                                 starts at that byte                                                                            */
 };
 
 typedef struct milzma_result {
@@ -109,7 +113,7 @@ typedef struct milzma_result {
   uint64_t err_a, err_b;
 } milzma_result;
 
-#define MILZMA_PARKED 1u /* milzma_result.err_a of a unit that stopped for room and can be resumed */
+#define MILZMA_PARKED 1u /* milzma_result.err_a of a unit that stopped for room (status OUT_FULL) or input (NEED_INPUT) and can be resumed */
 
 typedef struct milzma_ctx milzma_ctx;
 
@@ -168,9 +172,28 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *                         against what it recorded when it parked the units -- a unit that was not parked by the previous call, another
  *                         in_off / in_len / kind, an out_cap below the out_len it has produced: MILZMA_INFRA_ERROR, nothing launched,
  *                         the parked states stay -- and takes the launch class from its own record, not from `results`.
+ *   MILZMA_DECODE_FEED    (implies GROW) fed input -- the reference's streaming front end (`impl Write for Stream`, src/decode/stream.rs:223-283:
+ *                         the caller hands the compressed bytes over piece by piece; lzma.rs:435-524 `process_mode(Partial)` decodes
+ *                         a symbol only while MAX_REQUIRED_INPUT = 20 bytes are at hand or a trial run shows that fewer suffice).  Every unit's (in_off, in_len) is a VIEW: the bytes of its
+ *                         stream that are on the device so far.  A unit that comes within 32 bytes of its view's end stops at a
+ *                         symbol boundary (an LZMA2 unit also: in front of a packet header or a stored chunk that is not inside the
+ *                         view) and is parked with (MILZMA_ST_NEED_INPUT, err_a = MILZMA_PARKED, in_consumed = bytes of THIS view it
+ *                         has used, out_len = bytes produced so far).  EVERY unit a FEED call parks -- for input or, as under GROW,
+ *                         for room (MILZMA_ST_OUT_FULL) -- is resumed (RESUME | FEED, or plain RESUME when no stream has more to
+ *                         come) with a descriptor whose view starts at its first unused byte: the bytes from in_off + in_consumed
+ *                         on, wherever the caller has them now in (the new) d_in -- the unused tail moved in front of the newly
+ *                         arrived bytes of a ring, or simply a longer view of the same buffer.  A view may be of any length, also
+ *                         empty; in_consumed of every result counts from the start of the view of its own call.  A unit whose view
+ *                         ends where its stream ends carries MILZMA_KIND_LAST_VIEW in `kind`: it is decoded to its end like any
+ *                         unit (a stream that ends early is the reference's UnexpectedEof there, reader position and delivered
+ *                         bytes included); a call without the FEED flag treats every view as the last.  An end marker / declared
+ *                         size / LZMA2 end byte met inside a view ends the unit as usual.  Asm-kernel classes only (a context under
+ *                         MILZMA_KERNEL / MILZMA_SPILL = generic refuses the flag); LZMA2 units run with a literal-row slab (a
+ *                         property switch can be followed without decoding again from a start that is no longer there).
  * Parked states live until the next decode call on the context that is not a RESUME. */
 #define MILZMA_DECODE_GROW 1u
 #define MILZMA_DECODE_RESUME 2u
+#define MILZMA_DECODE_FEED 4u
 int milzma_decode_units_ex(milzma_ctx *ctx, const milzma_unit *units, uint32_t n, const void *d_in,
                            void *d_out, milzma_result *results, void *hip_stream, uint32_t flags);
 

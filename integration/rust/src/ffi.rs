@@ -16,6 +16,8 @@ pub const MILZMA_INFRA_ERROR: c_int = 5;
 
 pub const MILZMA_KIND_RAW_LZMA: u8 = 0;
 pub const MILZMA_KIND_LZMA2: u8 = 1;
+/// or-ed into `milzma_unit.kind` in a `MILZMA_DECODE_FEED` call: this unit's view ends where its stream ends
+pub const MILZMA_KIND_LAST_VIEW: u8 = 0x80;
 pub const MILZMA_SIZE_UNKNOWN: u64 = u64::MAX;
 pub const MILZMA_NO_LIMIT: u64 = u64::MAX;
 pub const MILZMA_MAX_UNIT_BYTES: u64 = 0xFFFF_FF00;
@@ -27,10 +29,14 @@ pub const MILZMA_USE_PROVIDED: i32 = 2;
 
 pub const MILZMA_ST_OK: u32 = 0;
 pub const MILZMA_ST_OUT_FULL: u32 = 32;
+/// `MILZMA_DECODE_FEED`: the unit stopped within 32 bytes of the end of its input view (`err_a == MILZMA_PARKED`)
+pub const MILZMA_ST_NEED_INPUT: u32 = 37;
 /// `milzma_result.err_a` of a unit that stopped for room and can be resumed (MILZMA_DECODE_RESUME)
 pub const MILZMA_PARKED: u64 = 1;
 pub const MILZMA_DECODE_GROW: u32 = 1;
 pub const MILZMA_DECODE_RESUME: u32 = 2;
+/// fed input: every unit's (in_off, in_len) is a view of a stream that goes on behind it (include/milzma.h)
+pub const MILZMA_DECODE_FEED: u32 = 4;
 pub const MILZMA_PATH_STREAMED: u32 = 1;
 pub const MILZMA_PATH_TWO_PART_INPUT: u32 = 2;
 pub const MILZMA_PATH_CLASSIC: u32 = 4;

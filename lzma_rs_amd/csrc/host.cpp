@@ -436,7 +436,7 @@ bool ensure_progress(milzma_ctx* ctx) {
 
 // Launches `order` (unit indices) in class `cls`; kernel time is accumulated into ctx.
 bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& order, uint32_t order_base,
-                  const uint8_t* d_in, uint8_t* d_out, hipStream_t stream, bool grow = false, bool resume = false) {
+                  const uint8_t* d_in, uint8_t* d_out, hipStream_t stream, bool grow = false, bool resume = false, bool feed = false) {
   if (order.empty()) return true;
   auto* d_units = static_cast<const milzma_unit*>(ctx->units.p);
   auto* d_order = static_cast<const uint32_t*>(ctx->order.p) + order_base;
@@ -473,6 +473,10 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
         ctx->err = keep;
         if (resume) {   // (units parked in this class without a live slab: the context was used for something else in between)
           ctx->err = "no literal-row slab for the parked units";
+          return false;
+        }
+        if (feed) {   // (the generic kernel cannot park a unit)
+          ctx->err = "MILZMA_DECODE_FEED: no memory for the literal-row slab of the fed units";
           return false;
         }
         return launch_class(ctx, kLitSpill, order, order_base, d_in, d_out, stream);
@@ -556,7 +560,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     const hipError_t le = sliced
                               ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad,
                                                    static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
-                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow, ctx->stream_span, ctx->stream_spans,
+                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow, feed, ctx->stream_span, ctx->stream_spans,
                                                    ctx->stream_active ? ctx->progress_dev : nullptr, ctx->stream_active ? ctx->stream_host : nullptr,
                                                    ctx->stream_active && ctx->stream_in_host ? ctx->progress_dev + milzma_ctx::kMaxSpans : nullptr,
                                                    ctx->stream_active ? ctx->stream_ptrs : nullptr,
@@ -595,7 +599,12 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
                                           void* d_out, void* hip_stream, uint32_t flags, const milzma_result* prev) {
   if (!ctx) return MILZMA_INFRA_ERROR;
   const bool resume = (flags & MILZMA_DECODE_RESUME) != 0;
-  const bool grow = resume || (flags & MILZMA_DECODE_GROW) != 0;
+  const bool feed = (flags & MILZMA_DECODE_FEED) != 0;
+  const bool grow = resume || feed || (flags & MILZMA_DECODE_GROW) != 0;
+  if (feed && !(ctx->use_fast && ctx->fast_spill)) {
+    ctx->err = "MILZMA_DECODE_FEED needs the asm kernel's launch classes (MILZMA_KERNEL / MILZMA_SPILL = generic set)";
+    return MILZMA_INFRA_ERROR;
+  }
   if (resume && (!ctx->parked_valid || ctx->parked_n != n || !prev)) {
     ctx->err = "MILZMA_DECODE_RESUME: this context holds no parked units of a batch of that size";
     return MILZMA_INFRA_ERROR;
@@ -616,7 +625,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   ctx->last_launches = 0;
   ctx->ev_used = 0;
   ctx->pend_n = n;
-  ctx->pend_flags = (grow ? MILZMA_DECODE_GROW : 0u) | (resume ? MILZMA_DECODE_RESUME : 0u);
+  ctx->pend_flags = (grow ? MILZMA_DECODE_GROW : 0u) | (resume ? MILZMA_DECODE_RESUME : 0u) | (feed ? MILZMA_DECODE_FEED : 0u);
   ctx->stream_active = false;
   ctx->promoted.clear();
   ctx->pending = true;
@@ -647,7 +656,14 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   // the same floor (the kernels divide by dict_size).
   ctx->pend_units.assign(units, units + n);
   for (milzma_unit& u : ctx->pend_units)
-    if (u.kind == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
+    if ((u.kind & (feed ? 0x7Fu : 0xFFu)) == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
+  // (fed input: MILZMA_KIND_LAST_VIEW is for the kernel; everything on the host side looks at the plain kind)
+  ctx->feed_units.clear();
+  if (feed) {
+    ctx->feed_units = ctx->pend_units;
+    for (milzma_unit& u : ctx->pend_units) u.kind &= uint8_t(~MILZMA_KIND_LAST_VIEW);
+  }
+  const milzma_unit* const units_up = feed ? ctx->feed_units.data() : ctx->pend_units.data();
   units = ctx->pend_units.data();
 
   // Partition by launch class; inside a class longest input first, so that the hardware's
@@ -655,10 +671,14 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   std::vector<uint32_t> order[kNumLitClasses];
   if (resume) {  // only what the previous call parked, each unit in the class the CONTEXT knows it was parked in
     for (uint32_t i = 0; i < n; i++)
-      if (prev[i].status == MILZMA_ST_OUT_FULL && prev[i].err_a == MILZMA_PARKED) {
+      if (is_parked_result(prev[i])) {
+        // (a unit parked by a FEED call comes back with another view by design -- the caller vouches that it starts at the unit's first
+        //  unused byte, there is nothing here to hold that against)
         const milzma_ctx::ParkRec* rec = i < ctx->park_rec.size() ? &ctx->park_rec[i] : nullptr;
+        const bool same_view = rec && (rec->fed || (units[i].in_off == rec->in_off && units[i].in_len == rec->in_len));
         const char* why = !rec || !rec->parked                                                        ? "was not parked by the previous call"
-                          : units[i].in_off != rec->in_off || units[i].in_len != rec->in_len || units[i].kind != rec->kind ? "names another input than the one it was parked with"
+                          : (prev[i].status == MILZMA_ST_NEED_INPUT) != (rec->input != 0)             ? "was parked for another reason than its result says"
+                          : !same_view || units[i].kind != rec->kind                                  ? "names another input than the one it was parked with"
                           : units[i].out_cap < rec->out_len                                           ? "has a slice smaller than the output it has produced"
                                                                                                       : nullptr;
         if (why) {  // (nothing is launched: a descriptor that does not fit the parked state would write outside its slice)
@@ -669,7 +689,19 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
         order[rec->spill ? kFastSpill : kFast].push_back(i);
       }
   } else {
-    for (uint32_t i = 0; i < n; i++) order[classify(ctx, units[i])].push_back(i);
+    // (fed LZMA2 units: with a slab from the start -- a property switch beyond lc + lp = 3 cannot send them back to a start that has gone)
+    for (uint32_t i = 0; i < n; i++) {
+      LitClass c = classify(ctx, units[i]);
+      if (feed && c == kFast && units[i].kind == MILZMA_KIND_LZMA2) c = kFastSpill;
+      order[c].push_back(i);
+    }
+    if (feed)
+      for (int c = 0; c < kNumLitClasses; c++)
+        if (c != kFast && c != kFastSpill && !order[c].empty()) {
+          ctx->err = "MILZMA_DECODE_FEED: unit " + std::to_string(order[c][0]) + " is outside the asm kernel's launch classes";
+          ctx->pending = false;
+          return MILZMA_INFRA_ERROR;
+        }
   }
   std::vector<uint32_t> flat;
   flat.reserve(n);
@@ -713,7 +745,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   // (the order array is staged in page-locked memory behind the results so that its upload is asynchronous too)
   uint32_t* h_order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->pin_results.p) + size_t(n) * sizeof(milzma_result));
   for (size_t k = 0; k < flat.size(); k++) h_order[k] = flat[k] | (resume ? 0x80000000u : 0u);  // (bit 31: resume from the parked state)
-  if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
+  if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units_up, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
               "H2D units") ||
       (!flat.empty() &&
        !hip_ok(ctx, hipMemcpyAsync(ctx->order.p, h_order, flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream), "H2D order")))
@@ -726,7 +758,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   }
 
   for (int c = 0; c < kNumLitClasses; c++)
-    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream, grow, resume)) return fail();
+    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream, grow, resume, feed)) return fail();
 
   // (The results are fetched by the wait half, after the kernels: a copy queued behind a running kernel parks a DMA queue on
   //  that kernel's completion, and an unrelated upload of another context that lands on the same queue then waits for the whole
@@ -787,7 +819,9 @@ int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results) {
                 "H2D order") ||
         !hip_ok(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize"))  // (`again` is pageable and about to go away)
       return bail();
-    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream, (ctx->pend_flags & MILZMA_DECODE_GROW) != 0)) return bail();
+    if (!launch_class(ctx, next, again, n, ctx->pend_in, ctx->pend_out, stream, (ctx->pend_flags & MILZMA_DECODE_GROW) != 0, false,
+                      (ctx->pend_flags & MILZMA_DECODE_FEED) != 0))
+      return bail();
     if (!hip_ok(ctx,
                 hipMemcpyAsync(results, ctx->results.p, size_t(n) * sizeof(milzma_result), hipMemcpyDeviceToHost, stream),
                 "D2H results") ||
@@ -796,15 +830,17 @@ int milzma_decode_units_wait_impl(milzma_ctx* ctx, milzma_result* results) {
   }
   if (ctx->pend_flags & MILZMA_DECODE_GROW) {
     bool any = false;
-    for (uint32_t i = 0; i < n && !any; i++) any = results[i].status == MILZMA_ST_OUT_FULL && results[i].err_a == MILZMA_PARKED;
+    for (uint32_t i = 0; i < n && !any; i++) any = is_parked_result(results[i]);
     ctx->parked_valid = any;
     ctx->parked_n = n;
     if (!any) ctx->slab_live = false;
     ctx->park_rec.assign(any ? n : 0, milzma_ctx::ParkRec());
     for (uint32_t i = 0; any && i < n; i++)
-      if (results[i].status == MILZMA_ST_OUT_FULL && results[i].err_a == MILZMA_PARKED) {
+      if (is_parked_result(results[i])) {
         milzma_ctx::ParkRec& r = ctx->park_rec[i];
         r.parked = 1;
+        r.input = results[i].status == MILZMA_ST_NEED_INPUT;
+        r.fed = (ctx->pend_flags & MILZMA_DECODE_FEED) != 0;
         r.spill = (results[i].err_b & 0x100) ? 1 : 0;
         r.kind = uint8_t(ctx->pend_units[i].kind);
         r.in_off = ctx->pend_units[i].in_off;
@@ -926,6 +962,7 @@ extern "C" int milzma_result_message(const milzma_result* r, uint32_t unit_kind,
     case MILZMA_ST_BAD_UNIT: return render(msg, cap, MILZMA_INFRA_ERROR, "bad unit descriptor");
     case MILZMA_ST_NEED_GENERIC: return render(msg, cap, MILZMA_INFRA_ERROR, "properties outside the fast kernel's class");
     case MILZMA_ST_NEED_RERUN: return render(msg, cap, MILZMA_INFRA_ERROR, "unit outran its input upload");
+    case MILZMA_ST_NEED_INPUT: return render(msg, cap, MILZMA_INFRA_ERROR, "unit parked at the end of its input view");
     default: return render(msg, cap, MILZMA_INFRA_ERROR, "unknown status %u", r->status);
   }
 }

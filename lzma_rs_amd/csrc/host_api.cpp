@@ -39,7 +39,7 @@ extern "C" int milzma_decode_units_ex(milzma_ctx* ctx, const milzma_unit* units,
                                       milzma_result* results, void* hip_stream, uint32_t flags) {
   begin_call(ctx);
   try {
-    if (ctx && (flags & ~(MILZMA_DECODE_GROW | MILZMA_DECODE_RESUME))) {
+    if (ctx && (flags & ~(MILZMA_DECODE_GROW | MILZMA_DECODE_RESUME | MILZMA_DECODE_FEED))) {
       ctx->err = "unknown flags";
       return MILZMA_INFRA_ERROR;
     }

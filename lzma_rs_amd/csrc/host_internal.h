@@ -77,6 +77,10 @@ struct PinLease {
 };
 extern thread_local std::string g_create_error;   // what milzma_last_error(nullptr) returns: the calling thread's last failed create
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// a unit the time-sliced kernel parked: for room (MILZMA_DECODE_GROW) or for input (MILZMA_DECODE_FEED)
+inline bool is_parked_result(const milzma_result& r) {
+  return (r.status == MILZMA_ST_OUT_FULL || r.status == MILZMA_ST_NEED_INPUT) && r.err_a == MILZMA_PARKED;
+}
 MILZMA_HOST_NS_END
 
 using milzma::host::DevBuf;
@@ -119,8 +123,11 @@ struct milzma_ctx {
   struct ParkRec {
     uint64_t in_off = 0, in_len = 0, out_len = 0;
     uint8_t parked = 0, spill = 0, kind = 0;
+    uint8_t input = 0;   // parked for input (MILZMA_ST_NEED_INPUT), not for room
+    uint8_t fed = 0;     // ... by a call with MILZMA_DECODE_FEED: its view is expected to change
   };
   std::vector<ParkRec> park_rec;
+  std::vector<milzma_unit> feed_units;   // MILZMA_DECODE_FEED: the descriptors as the device gets them (with MILZMA_KIND_LAST_VIEW)
   // The literal-row slab of class kFastSpill lives in `scratch`, indexed by unit with ONE stride for the whole batch.  While units of a
   // GROW batch are (or may still get) parked their trained rows exist only there: slab_live pins the stride (slab_lclp) and the
   // allocation until the parking lot is given up -- a RESUME launch or a promotion launch sees only a subset of the units and must

@@ -42,7 +42,7 @@ size_t slice_ctx_bytes();  // per unit, the same for both instantiations
 size_t slice_queue_bytes(uint32_t cap);
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t span_bytes = 0,
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, bool feed, uint32_t span_bytes = 0,
                               uint32_t n_spans = 0, uint32_t* progress = nullptr, uint8_t* host_out = nullptr, uint32_t* in_ready = nullptr,
                               const uint64_t* host_ptrs = nullptr, const uint8_t* d_slab = nullptr, uint32_t slab_bytes = 0);
 // host_ptrs (device array, one entry per unit of the batch, or null): the unit's own destination in host memory (0: none)
@@ -53,6 +53,8 @@ uint32_t stream_lead_bytes(uint32_t in_len);
 // span by span; progress: n_spans counters in such memory, counter s = units whose span s has arrived (see SliceQueue)
 // grow: growable output (milzma_decode_units_ex) -- a unit that runs out of room is parked in d_ctxmem with status OUT_FULL /
 // err_a = MILZMA_PARKED; d_order entries with bit 31 set resume such a unit (parked by an earlier launch with the same d_ctxmem)
+// feed: fed input (MILZMA_DECODE_FEED) -- a unit that comes within 32 bytes of the end of its input view is parked the same way with
+// status NEED_INPUT; resumed, its reader moves to the start of the view its descriptor then names
 
 // every probability (u16) of the literal-row slabs of the units d_order[0 .. n) = 0x400: d_slab + unit * slab_bytes, slab_bytes each.  Only
 // THOSE units' rows: other units of the batch may be parked with their trained rows in the same slab (bit 31 of an entry is ignored).

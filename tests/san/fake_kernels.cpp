@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -62,11 +64,30 @@ uint32_t first_lclp(const uint8_t* in, size_t n) {
 
 constexpr uint64_t kRowsMagic = 0x524f57535f4f4b21ull;   // what a parked unit's rows look like in the slab: {magic, unit, stride}
 
-void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_t* d_out, milzma_result* res, bool grow, const Streamed* st,
-                const uint8_t* d_slab, uint32_t slab_bytes, bool resume) {
+// Fed input (MILZMA_DECODE_FEED): what a real parked unit keeps in registers -- everything it has consumed so far -- the stand-in keeps as
+// BYTES, per parking lot and unit: a view that is not the last is consumed up to 31 bytes before its end and the unit parks (NEED_INPUT),
+// the last view is decoded by the oracle behind everything kept.  What this exercises is the host side: the flag on its way to the
+// launch, the descriptors as uploaded (MILZMA_KIND_LAST_VIEW), the previous results uploaded before a resuming launch, the parked-unit
+// record and its checks.
+std::mutex g_fed_mu;
+std::map<std::pair<const void*, uint32_t>, std::vector<uint8_t>> g_fed;
+
+void decode_one(const milzma_unit& u_in, uint32_t uidx, const uint8_t* d_in, uint8_t* d_out, milzma_result* res, bool grow, const Streamed* st,
+                const uint8_t* d_slab, uint32_t slab_bytes, bool resume, bool feed = false, const void* lot = nullptr) {
   const bool has_slab = d_slab != nullptr;
+  milzma_unit u = u_in;
   milzma_result r;
   memset(&r, 0, sizeof r);
+  const bool last_view = feed && (u.kind & MILZMA_KIND_LAST_VIEW);
+  if (feed) u.kind &= uint8_t(~MILZMA_KIND_LAST_VIEW);
+  std::vector<uint8_t> kept;   // (what the unit consumed in earlier views)
+  const bool was_fed = resume && (res[uidx].err_b & 0x200u) && res[uidx].err_a == MILZMA_PARKED;
+  {
+    std::lock_guard<std::mutex> g(g_fed_mu);
+    auto it = g_fed.find({lot, uidx});
+    if (was_fed && it != g_fed.end()) kept = it->second;
+    if (it != g_fed.end() && !was_fed) g_fed.erase(it);
+  }
   uint64_t* rows = has_slab && slab_bytes >= 64 ? reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(d_slab) + size_t(uidx) * slab_bytes) : nullptr;
   if (rows) {  // the rows must be what the kernel's contract says: fresh for a first launch, this unit's own for a resumed one
     const uint64_t fresh = 0x0400040004000400ull;
@@ -82,6 +103,33 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
   orc_result o;
   memset(&o, 0, sizeof o);
   const uint8_t* in = d_in + u.in_off;
+  if (feed && !last_view) {   // parks within 32 bytes of the view's end; its rows stay in the slab
+    const uint64_t take = u.in_len > 31 ? u.in_len - 31 : 0;
+    kept.insert(kept.end(), in, in + take);
+    {
+      std::lock_guard<std::mutex> g(g_fed_mu);
+      g_fed[{lot, uidx}] = kept;
+    }
+    r.status = MILZMA_ST_NEED_INPUT;
+    r.err_a = MILZMA_PARKED;
+    r.err_b = (has_slab ? 0x100u : 0u) | 0x200u;
+    r.in_consumed = take;
+    if (rows) {
+      rows[0] = kRowsMagic;
+      rows[1] = uidx;
+      rows[2] = slab_bytes;
+      rows[slab_bytes / 8 - 1] = kRowsMagic;
+    }
+    res[uidx] = r;
+    return;
+  }
+  std::vector<uint8_t> joined;
+  if (!kept.empty()) {   // the last view behind everything consumed before: the stream from its first byte
+    joined = kept;
+    joined.insert(joined.end(), in, in + u.in_len);
+    in = joined.data();
+    u.in_len = joined.size();
+  }
   // like the fast kernel without a literal-row slab: an LZMA2 unit whose chunk asks for lc + lp = 4 is sent back for another launch class
   if (u.kind == MILZMA_KIND_LZMA2 && !has_slab && first_lclp(in, size_t(u.in_len)) == 4) {
     r.status = MILZMA_ST_NEED_GENERIC;
@@ -101,7 +149,7 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
   if (kind == ORC_OK && o.out_len > u.out_cap) {  // does not fit: parked in front of the symbol that would not (here: a little before the end)
     r.status = MILZMA_ST_OUT_FULL;
     r.err_a = grow ? MILZMA_PARKED : 0;
-    r.err_b = grow && has_slab ? 0x100u : 0u;   // (the launch class it resumes in, as the real kernel reports it)
+    r.err_b = (grow && has_slab ? 0x100u : 0u) | (grow && feed ? 0x200u : 0u);   // (the launch class it resumes in, as the real kernel reports it; 0x200: on a re-based view)
     if (grow && rows) {
       rows[0] = kRowsMagic;
       rows[1] = uidx;
@@ -114,7 +162,7 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
   } else {
     visible = size_t(o.out_len < u.out_cap ? o.out_len : u.out_cap);
     r.out_len = r.out_flushed = visible;
-    r.in_consumed = o.in_consumed;
+    r.in_consumed = o.in_consumed >= kept.size() ? o.in_consumed - kept.size() : 0;   // (counted from the start of THIS view)
     // the oracle's message back to the status (and the integers) the kernels report for that error site: milzma_result_message's inverse
     unsigned long long a = 0, b = 0;
     const char* m = strchr(o.msg, ':');
@@ -158,7 +206,7 @@ void decode_one(const milzma_unit& u, uint32_t uidx, const uint8_t* d_in, uint8_
 }
 
 void run_units(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out, milzma_result* d_results,
-               bool grow, Streamed st, const uint8_t* d_slab, uint32_t slab_bytes = 0) {
+               bool grow, Streamed st, const uint8_t* d_slab, uint32_t slab_bytes = 0, bool feed = false, const void* lot = nullptr) {
   if (st.in_ready)
     while (__atomic_load_n(st.in_ready, __ATOMIC_ACQUIRE) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
   // a few host threads stand for the chip: units really finish in any order and at the same time
@@ -167,7 +215,8 @@ void run_units(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, 
   const auto body = [&](unsigned k) {
     for (uint32_t i = k; i < n; i += t) {
       const uint32_t uidx = d_order[i] & 0x7FFFFFFFu;
-      decode_one(d_units[uidx], uidx, d_in, d_out, d_results, grow, st.progress ? &st : nullptr, d_slab, slab_bytes, (d_order[i] & 0x80000000u) != 0);
+      decode_one(d_units[uidx], uidx, d_in, d_out, d_results, grow, st.progress ? &st : nullptr, d_slab, slab_bytes, (d_order[i] & 0x80000000u) != 0,
+                 feed, lot);
     }
   };
   for (unsigned k = 1; k < t; k++) th.emplace_back(body, k);
@@ -196,7 +245,7 @@ uint32_t fast_resident_blocks(uint32_t) { return 16; }   // (a small chip: launc
 size_t slice_ctx_bytes() { return 64; }
 size_t slice_queue_bytes(uint32_t cap) { return size_t(cap) * 8 + 64; }
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                              milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool grow,
+                              milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void* d_ctxmem, bool grow, bool feed,
                               uint32_t span_bytes, uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready,
                               const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t slab_bytes) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
@@ -207,7 +256,7 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
   st.host_out = host_out;
   st.in_ready = in_ready;
   st.host_ptrs = host_ptrs;
-  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, grow, st, d_slab, slab_bytes); });
+  fake_hip_enqueue(stream, [=] { run_units(d_units, d_order, n, d_in, d_out, d_results, grow, st, d_slab, slab_bytes, feed, d_ctxmem); });
   return hipSuccess;
 }
 uint32_t stream_lead_bytes(uint32_t in_len) {

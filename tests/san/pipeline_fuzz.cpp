@@ -279,6 +279,169 @@ bool raw_grow_loop(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, const st
   return ok;
 }
 
+// 3d. fed input (MILZMA_DECODE_FEED): good .lzma payloads and LZMA2 streams arrive in three pieces, every view re-located into a fresh input
+// buffer from the unit's first unused byte; some units start in slices that are too small as well (both parking reasons in one batch).
+// The stand-in kernels keep what a unit has consumed as bytes (fake_kernels.cpp); what is under test is the host side: flags, descriptors as
+// uploaded, previous results before a resuming launch, the parked-unit record -- and its refusals.
+bool raw_feed_loop(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, const std::vector<Case>& lzma2_pool) {
+  struct Item {
+    const Case* c;
+    milzma_unit u;
+    size_t hdr;
+    orc_result want;
+    uint64_t used = 0;
+  };
+  std::vector<Item> items;
+  for (const Case& c : lzma_pool) {
+    if (items.size() >= 24) break;
+    Item it;
+    it.c = &c;
+    memset(&it.u, 0, sizeof it.u);
+    memset(&it.want, 0, sizeof it.want);
+    size_t hl = 0;
+    milzma_output ho;
+    memset(&ho, 0, sizeof ho);
+    if (milzma_lzma_read_header(ptr_of(c.data), c.data.size(), nullptr, &it.u, &hl, &ho) != MILZMA_OK) continue;
+    orc_lzma_decompress(ptr_of(c.data), c.data.size(), nullptr, &it.want);
+    if (it.want.kind != ORC_OK || c.data.size() - hl < 200) {
+      orc_free(it.want.out);
+      continue;
+    }
+    it.hdr = hl;
+    items.push_back(it);
+  }
+  for (const Case& c : lzma2_pool) {
+    if (items.size() >= 30) break;
+    Item it;
+    it.c = &c;
+    memset(&it.u, 0, sizeof it.u);
+    memset(&it.want, 0, sizeof it.want);
+    if (c.name.find('(') != std::string::npos) continue;
+    orc_lzma2_decompress(ptr_of(c.data), c.data.size(), &it.want);
+    if (it.want.kind != ORC_OK || c.data.size() < 200) {
+      orc_free(it.want.out);
+      continue;
+    }
+    it.u.kind = MILZMA_KIND_LZMA2;
+    it.hdr = 0;
+    items.push_back(it);
+  }
+  bool ok = true;
+  const uint32_t n = uint32_t(items.size());
+  if (n) {
+    std::vector<milzma_unit> units(n);
+    std::vector<milzma_result> res(n);
+    size_t oo = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      units[i] = items[i].u;
+      units[i].out_off = oo;
+      units[i].out_cap = i % 4 == 3 ? 500 : items[i].want.out_len + 300;   // (every fourth also parks for room once the oracle sees its last view)
+      oo += (size_t(units[i].out_cap) + 255) & ~size_t(255);
+    }
+    std::vector<uint8_t> out(oo + 512, 0), in;
+    uint32_t input_parks = 0, room_parks = 0;
+    bool refused_checked = false;
+    for (int round = 0; ok && round < 12; round++) {
+      // the views of this round: a third / two thirds / all of every stream (later rounds: all), from the first unused byte, at a new place
+      size_t io = size_t(round) * 7 + 3;
+      in.assign(in.size(), 0);
+      std::vector<uint8_t> fresh;
+      bool any = false;
+      for (uint32_t i = 0; i < n; i++) {
+        const bool parked = round == 0 || ((res[i].status == MILZMA_ST_NEED_INPUT || res[i].status == MILZMA_ST_OUT_FULL) && res[i].err_a == MILZMA_PARKED);
+        if (!parked) {
+          units[i].kind = items[i].u.kind;
+          continue;
+        }
+        any = true;
+        const size_t len = items[i].c->data.size() - items[i].hdr;
+        const size_t upto = round == 0 ? len / 3 : round == 1 ? len * 2 / 3 : len;
+        const size_t from = size_t(items[i].used);
+        units[i].in_off = io;
+        units[i].in_len = upto > from ? upto - from : 0;
+        units[i].kind = uint8_t(items[i].u.kind | (upto == len ? MILZMA_KIND_LAST_VIEW : 0));
+        fresh.resize(io + size_t(units[i].in_len) + 64, 0);
+        if (units[i].in_len) memcpy(fresh.data() + io, ptr_of(items[i].c->data) + items[i].hdr + from, size_t(units[i].in_len));
+        io += size_t(units[i].in_len) + 1 + (i % 5);
+      }
+      if (!any) break;
+      fresh.resize(io + 512, 0);
+      in.swap(fresh);
+      if (round > 0 && !refused_checked) {   // a RESUME whose results claim another parking reason than the context recorded is refused
+        refused_checked = true;
+        std::vector<milzma_result> lie = res;
+        for (uint32_t i = 0; i < n; i++)
+          if (lie[i].status == MILZMA_ST_NEED_INPUT && lie[i].err_a == MILZMA_PARKED) {
+            lie[i].status = MILZMA_ST_OUT_FULL;
+            break;
+          }
+        if (milzma_decode_units_ex(ctx, units.data(), n, in.data(), out.data(), lie.data(), nullptr, MILZMA_DECODE_RESUME | MILZMA_DECODE_FEED) !=
+            MILZMA_INFRA_ERROR) {
+          printf("MISMATCH a RESUME that lies about a unit's parking reason was not refused\n");
+          ok = false;
+          break;
+        }
+      }
+      if (milzma_decode_units_ex(ctx, units.data(), n, in.data(), out.data(), res.data(), nullptr,
+                                 MILZMA_DECODE_FEED | (round ? MILZMA_DECODE_RESUME : 0u)) != MILZMA_OK) {
+        printf("INFRA raw feed loop, round %d: %s\n", round, milzma_last_error(ctx));
+        ok = false;
+        break;
+      }
+      std::vector<uint64_t> so, dof, ln;
+      std::vector<milzma_unit> next = units;
+      size_t total = 0;
+      bool room = false;
+      for (uint32_t i = 0; i < n; i++) {
+        const bool pin = res[i].status == MILZMA_ST_NEED_INPUT && res[i].err_a == MILZMA_PARKED;
+        const bool prm = res[i].status == MILZMA_ST_OUT_FULL && res[i].err_a == MILZMA_PARKED;
+        if ((pin || prm) && (units[i].kind & MILZMA_KIND_LAST_VIEW ? pin : false)) {
+          printf("MISMATCH unit %u parked for input on its last view\n", i);
+          ok = false;
+        }
+        if (pin || prm) items[i].used += res[i].in_consumed;
+        input_parks += pin;
+        room_parks += prm;
+        room = room || prm;
+        next[i].out_off = total;
+        next[i].out_cap = prm ? items[i].want.out_len + 300 : units[i].out_cap;
+        so.push_back(units[i].out_off);
+        dof.push_back(total);
+        ln.push_back(res[i].out_len < units[i].out_cap ? res[i].out_len : units[i].out_cap);
+        total += (size_t(next[i].out_cap) + 255) & ~size_t(255);
+      }
+      if (room) {
+        std::vector<uint8_t> bigger(total + 512, 0);
+        if (milzma_move_units(ctx, n, out.data(), so.data(), bigger.data(), dof.data(), ln.data(), nullptr) != MILZMA_OK) {
+          printf("INFRA move_units (raw feed loop): %s\n", milzma_last_error(ctx));
+          ok = false;
+          break;
+        }
+        out.swap(bigger);
+        units = next;
+      }
+    }
+    for (uint32_t i = 0; i < n && ok; i++) {
+      g_cases++;
+      g_compared++;
+      const orc_result& w = items[i].want;
+      const uint64_t reader = items[i].used + res[i].in_consumed + items[i].hdr;
+      if (res[i].status != MILZMA_ST_OK || res[i].out_len != w.out_len || memcmp(out.data() + units[i].out_off, w.out, w.out_len) != 0 ||
+          reader != w.in_consumed) {
+        printf("MISMATCH fed unit %u (%s): status %u len %" PRIu64 " (want %zu) reader %" PRIu64 " (want %zu)\n", i, items[i].c->name.c_str(), res[i].status,
+               res[i].out_len, w.out_len, reader, w.in_consumed);
+        ok = false;
+      }
+    }
+    if (ok && (input_parks < n || room_parks == 0)) {
+      printf("MISMATCH the raw feed loop parked %u times for input, %u for room (%u units)\n", input_parks, room_parks, n);
+      ok = false;
+    }
+  }
+  for (Item& it : items) orc_free(it.want.out);
+  return ok;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -646,6 +809,7 @@ int main(int argc, char** argv) {
     }
     for (auto& w : want) orc_free(w.out);
     if (ok) ok = raw_grow_loop(ctx, pool[LZMA], pool[LZMA2]);
+    if (ok) ok = raw_feed_loop(ctx, pool[LZMA], pool[LZMA2]);
     // milzma_xz_plan: the Index of a good file -> one unit per block; decoded, every block's bytes where the plan put them
     for (const Case& c : pool[XZ]) {
       if (!ok) break;

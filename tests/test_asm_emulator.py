@@ -209,7 +209,9 @@ def test_emulated_loop_fed_in_views(loops, lc, lp, pb):
         plain = W.make_plain(kind, size, seed=77 + size)
         comp = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=known)
         pay = comp[13:]
-        cuts = sorted(set(rng.randrange(1, len(pay)) for _ in range(14)) | set(range(200, min(len(pay), 232))))   # (32 views one byte apart)
+        # (many views: the dangerous stop is the one whose view ends 33 .. 95 bytes into its last-but-one window -- the symbol that starts
+        #  near that window's end must not be begun; plus 32 views one byte apart)
+        cuts = sorted(set(rng.randrange(16, len(pay)) for _ in range(260)) | set(range(200, min(len(pay), 232))))
         r = loop.decode_raw(pay, lc, lp, pb, 1 << 16, len(plain) if known else None, out_cap=len(plain) + 300, feed_views=cuts)
         ref = orc.lzma_decompress(comp)
         assert r["status"] == "OK" and r["out"] == plain and r["in_consumed"] + 13 == ref.in_consumed, (kind, known)

@@ -390,60 +390,66 @@ def test_truncated_at_every_length(ctx):
         same(d, orc.lzma_decompress(c))
 
 
+LZMA2_PROPS_POOL = [(3, 0, 2), (3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (4, 0, 2), (0, 4, 1)]
+
+
+def random_lzma2_stream(rng, max_chunks=7, max_syms=120, props_pool=LZMA2_PROPS_POOL):
+    """One LZMA2 stream of random packets: LZMA chunks that end at arbitrary symbols (every control byte the format has, properties from
+    `props_pool`), stored chunks and dictionary resets in between; ends with the end byte."""
+    lc, lp, pb = rng.choice(props_pool)
+    enc = E.LzmaSymbolEncoder(lc, lp, pb)
+    stream = b""
+    first, props_sent = True, False
+    for chunk in range(rng.randint(1, max_chunks)):
+        r = rng.random()
+        if r < 0.25:
+            data = bytes(rng.randrange(256) for _ in range(rng.randint(1, 300)))
+            reset = first or rng.random() < 0.2
+            enc.stored(data, reset)
+            stream += E.lzma2_stored_chunk(data, reset)
+            first = False
+            continue
+        if first:
+            control = 0xE0
+        elif not props_sent:
+            control = rng.choice([0xC0, 0xE0])  # the first LZMA chunk has to carry the properties
+        else:
+            control = rng.choice([0x80, 0x80, 0xA0, 0xC0, 0xE0])
+        props_sent = True
+        props = None
+        if control >= 0xC0:
+            lc, lp, pb = rng.choice(props_pool)
+            props = E.props_byte(lc, lp, pb)
+        if control >= 0xA0:
+            enc.reset_state(lc, lp, pb)
+        if control == 0xE0:
+            enc.stored(b"", True)
+        before = enc.total_len
+        n = len(enc.out)
+        for _ in range(rng.randint(1, max_syms)):
+            r = rng.random()
+            if n == 0 or r < 0.45:
+                sym = ("lit", rng.randrange(256))
+            elif r < 0.75:
+                sym = ("match", rng.randint(2, rng.choice([4, 30, 273])), rng.randint(1, n))
+            elif r < 0.9:
+                idx = rng.randint(0, 3)
+                sym = ("rep", idx, rng.randint(2, 90)) if enc.rep[idx] + 1 <= n else ("lit", 1)
+            else:
+                sym = ("shortrep",) if enc.rep[0] + 1 <= n else ("lit", 2)
+            enc.encode([sym])
+            n = len(enc.out)
+        payload = enc.take_chunk()
+        stream += E.lzma2_lzma_chunk(payload, enc.total_len - before, control, props=props)
+        first = False
+    return stream + b"\x00"
+
+
 def test_lzma2_random_chunk_sequences(ctx):
     # chunk boundaries at arbitrary symbols: state, reps and the literal context cross from one range
     # coder to the next; stored chunks and dictionary resets in between (lzma2.rs:84-229)
     rng = random.Random(77)
-    props_pool = [(3, 0, 2), (3, 0, 2), (0, 0, 0), (1, 2, 1), (2, 1, 2), (0, 3, 0), (4, 0, 2), (0, 4, 1)]
-    cases = []
-    for trial in range(40):
-        lc, lp, pb = rng.choice(props_pool)
-        enc = E.LzmaSymbolEncoder(lc, lp, pb)
-        stream = b""
-        first, props_sent = True, False
-        for chunk in range(rng.randint(1, 7)):
-            r = rng.random()
-            if r < 0.25:
-                data = bytes(rng.randrange(256) for _ in range(rng.randint(1, 300)))
-                reset = first or rng.random() < 0.2
-                enc.stored(data, reset)
-                stream += E.lzma2_stored_chunk(data, reset)
-                first = False
-                continue
-            if first:
-                control = 0xE0
-            elif not props_sent:
-                control = rng.choice([0xC0, 0xE0])  # the first LZMA chunk has to carry the properties
-            else:
-                control = rng.choice([0x80, 0x80, 0xA0, 0xC0, 0xE0])
-            props_sent = True
-            props = None
-            if control >= 0xC0:
-                lc, lp, pb = rng.choice(props_pool)
-                props = E.props_byte(lc, lp, pb)
-            if control >= 0xA0:
-                enc.reset_state(lc, lp, pb)
-            if control == 0xE0:
-                enc.stored(b"", True)
-            before = enc.total_len
-            n = len(enc.out)
-            for _ in range(rng.randint(1, 120)):
-                r = rng.random()
-                if n == 0 or r < 0.45:
-                    sym = ("lit", rng.randrange(256))
-                elif r < 0.75:
-                    sym = ("match", rng.randint(2, rng.choice([4, 30, 273])), rng.randint(1, n))
-                elif r < 0.9:
-                    idx = rng.randint(0, 3)
-                    sym = ("rep", idx, rng.randint(2, 90)) if enc.rep[idx] + 1 <= n else ("lit", 1)
-                else:
-                    sym = ("shortrep",) if enc.rep[0] + 1 <= n else ("lit", 2)
-                enc.encode([sym])
-                n = len(enc.out)
-            payload = enc.take_chunk()
-            stream += E.lzma2_lzma_chunk(payload, enc.total_len - before, control, props=props)
-            first = False
-        cases.append(stream + b"\x00")
+    cases = [random_lzma2_stream(rng) for trial in range(40)]
     for comp, d in zip(cases, ctx.lzma2_batch(cases)):
         ref = orc.lzma2_decompress(comp)
         same(d, ref)

@@ -183,7 +183,7 @@ VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 # aligned + 0 / 2 dwords 224.5 ms, + 4 / 6 dwords 222.4, + 8 / 10 225.0, + 12 / 14 223.0: period 32 bytes).  Left to wherever the compiler's code in front
 # of the asm statement ends, the phase changed with every edit of the C++ around the loop; pinned: 32-byte aligned + 6 dwords (221.8 ms; + 4: 222.0, + 5: 222.5, + 7: 223.4; unpinned as it happened to fall: 221.8).
 ALIGN = int(os.environ.get("MILZMA_GEN_ALIGN", "5"))   # log2 of the alignment of the loop's first instruction (0: wherever the compiler's code ends)
-ALIGN_PAD = int(os.environ.get("MILZMA_GEN_ALIGN_PAD", "6"))   # ... + this many 4-byte s_nop behind the alignment: the phase of the loop's code in its fetch lines
+ALIGN_PAD = int(os.environ.get("MILZMA_GEN_ALIGN_PAD", "3"))   # ... + this many 4-byte s_nop behind the alignment: the phase of the loop's code in its fetch lines
 STATE_TBL = os.environ.get("MILZMA_GEN_STATE_TBL", "0") == "1"   # (measured: 0.8 % slower on text, 3 % on random data -- off)
 DEFER = set(filter(None, re.split("[,+]", os.environ.get("MILZMA_GEN_DEFER", "single,tree"))))
 SHADOW = int(os.environ.get("MILZMA_GEN_SHADOW", "6"))   # (round 5: 6 instead of 4: -0.4 %, with and without SYM_M0)
@@ -240,11 +240,12 @@ CLOBBER_S = sorted((set(S.values()) | {"s90", "s91", "s92", "s93", "s98", "s99"}
 
 EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, MATCH_DIST_DICT=6,
             MATCH_DIST_OUT=7, LZ_DIST_DICT=8, LZ_DIST_OUT=9, QUANTUM=10, NEED_INPUT=11)
-# FEED (round 5, MILZMA_DECODE_FEED): bit 8 of the lc8 operand (the shift that uses it takes the low five bits) says that the input the reader
+# FEED (round 5, MILZMA_DECODE_FEED): bit 5 of the lc8 operand (the shift that uses it takes the low five bits) says that the input the reader
 # sees is a VIEW that will be continued: the loop then leaves at the first symbol top with fewer than FEED_MARGIN bytes of the view left
 # (exit NEED_INPUT: nothing of the next symbol looked at; the reference's Stream keeps 20 bytes back for the same reason, stream.rs) instead of
 # running a symbol into the end of the view.  Costs the ordinary loop two scalar instructions per window refill (set_guards).
-FEED_BIT = 8
+FEED = os.environ.get("MILZMA_GEN_FEED", "1") == "1"   # (0: the loop without it -- A/B of what its few scalar instructions and the shift of the code behind them cost)
+FEED_BIT = 5
 FEED_MARGIN = 32
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
@@ -884,9 +885,13 @@ class Gen:
         # no signed compares on it)
         if EOFWRAP:
             # every symbol looks closer once the reader is at EOF (lim = -1) -- with FEED: from the view's last window on (lim = 0, -1)
-            e("s_bfe_u32 {gdist}, {lc8}, 0x%x" % ((1 << 16) | FEED_BIT))    # (gdist: set below)
-            e("s_add_u32 {t}, {lim}, 1", t=t)
-            e("s_cmp_gt_u32 {t}, {gdist}", t=t)
+            if FEED:
+                assert (1 << FEED_BIT) == FEED_MARGIN
+                e("s_and_b32 {gdist}, {lc8}, %d" % FEED_MARGIN)    # (gdist: set below) 0, or FEED_MARGIN when the view will be continued
+                e("s_add_u32 {t}, {lim}, 1", t=t)
+                e("s_cmp_gt_u32 {t}, {gdist}", t=t)               # lim >= FEED_MARGIN: no symbol that starts in this window can reach the view's end
+            else:
+                e("s_cmp_lg_u32 {lim}, -1")                     # -1: the reader IS at EOF
         elif OFFBIAS:
             e("s_add_u32 {t}, {lim}, 64", t=t)
             e("s_cmpk_gt_u32 {t}, 63", t=t)
@@ -1232,15 +1237,13 @@ class Gen:
             e("s_cbranch_scc1 " + L("Xdone_size"))
             e("s_cmp_gt_u32 {len}, {safe_len}")           # from here on every match looks closer
             e("s_cselect_b32 {gdist}, 0, {gdist}")
-            if EOFWRAP:   # FEED: fewer than FEED_MARGIN bytes of the view left (lim = 0: the last window, -off of them left; -1: none)
+            if EOFWRAP and FEED:   # FEED: fewer than FEED_MARGIN bytes of the view left (lim = 0: the last window, -off of them left; -1: none)
                 e("s_bitcmp1_b32 {lc8}, %d" % FEED_BIT)
                 e("s_cbranch_scc0 " + L("Onofeed" + tag))
-                e("s_add_u32 {t0}, {lim}, 1")
-                e("s_cmp_gt_u32 {t0}, 1")
-                e("s_cbranch_scc1 " + L("Onofeed" + tag))
                 e("s_cmp_eq_u32 {lim}, -1")
                 e("s_cbranch_scc1 " + L("Xneed_input"))
-                e("s_cmp_gt_i32 {off}, %d" % -FEED_MARGIN)
+                e("s_sub_u32 {t0}, {lim}, {off}")                 # bytes of the view left: -off in this window, lim beyond it
+                e("s_cmp_lt_u32 {t0}, %d" % FEED_MARGIN)
                 e("s_cbranch_scc1 " + L("Xneed_input"))
                 lab("Onofeed" + tag)
             e("s_cmp_eq_u32 {off}, {lim}")                    # reader at EOF: the stream may be finished
@@ -2062,6 +2065,7 @@ def main():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
     out.append("#define MILZMA_LOOP_PEND_UNKNOWN 0x%xu" % PEND_UNKNOWN)
     out.append("#define MILZMA_LOOP_EXIT_RESEEK 0x100u   /* or-ed into the exit code: reload the input windows before reading on */")
+    out.append("#define MILZMA_LOOP_FEED_BIT 0x%xu   /* or-ed into the lc8 operand: leave (NEED_INPUT) at the first symbol top with fewer than %d bytes of the input view left */" % (1 << FEED_BIT, FEED_MARGIN))
     for name, lines in texts.items():
         out.append("#define MILZMA_FAST_LOOP_TEXT_%s \\" % name)
         if ALIGN:
