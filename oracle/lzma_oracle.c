@@ -1305,6 +1305,411 @@ int orc_xz_decompress(const uint8_t *in, size_t in_len, orc_result *res) {
 }
 
 /* ------------------------------------------------------------------ */
+/* Stream (feature `stream`), src/decode/stream.rs + the Partial mode   */
+/* of DecoderState::process_mode, src/decode/lzma.rs:395-524            */
+/* ------------------------------------------------------------------ */
+
+/* RangeDecoder::decode_bit with update = false (rangecoder.rs:92-120): the probability is read, not written. <0 => EOF */
+static inline int rc_peek_bit(rc_t *rc, uint16_t prob) {
+  uint32_t bound = (rc->range >> 11) * (uint32_t)prob;
+  if (rc->code < bound) {
+    rc->range = bound;
+    if (rc_normalize(rc)) return -1;
+    return 0;
+  }
+  rc->code -= bound;
+  rc->range -= bound;
+  if (rc_normalize(rc)) return -1;
+  return 1;
+}
+
+/* parse_bit_tree / parse_reverse_bit_tree with update = false (rangecoder.rs:122-151) */
+static int rc_peek_bit_tree(rc_t *rc, unsigned num_bits, const uint16_t *probs, uint32_t *out) {
+  uint32_t tmp = 1;
+  unsigned i;
+  for (i = 0; i < num_bits; i++) {
+    int bit = rc_peek_bit(rc, probs[tmp]);
+    if (bit < 0) return 1;
+    tmp = (tmp << 1) ^ (uint32_t)bit;
+  }
+  *out = tmp - (1u << num_bits);
+  return 0;
+}
+static int rc_peek_reverse_bit_tree(rc_t *rc, unsigned num_bits, const uint16_t *probs, size_t offset, uint32_t *out) {
+  uint32_t result = 0, tmp = 1;
+  unsigned i;
+  for (i = 0; i < num_bits; i++) {
+    int bit = rc_peek_bit(rc, probs[offset + tmp]);
+    if (bit < 0) return 1;
+    tmp = (tmp << 1) ^ (uint32_t)bit;
+    result ^= (uint32_t)bit << i;
+  }
+  *out = result;
+  return 0;
+}
+
+/* LenDecoder::decode with update = false (rangecoder.rs:256-269) */
+static int lendec_peek(const lendec_t *l, rc_t *rc, size_t pos_state, size_t *out) {
+  uint32_t v;
+  int bit = rc_peek_bit(rc, l->choice);
+  if (bit < 0) return 1;
+  if (!bit) {
+    if (rc_peek_bit_tree(rc, 3, l->low_coder[pos_state], &v)) return 1;
+    *out = v;
+    return 0;
+  }
+  bit = rc_peek_bit(rc, l->choice2);
+  if (bit < 0) return 1;
+  if (!bit) {
+    if (rc_peek_bit_tree(rc, 3, l->mid_coder[pos_state], &v)) return 1;
+    *out = (size_t)v + 8;
+    return 0;
+  }
+  if (rc_peek_bit_tree(rc, 8, l->high_coder, &v)) return 1;
+  *out = (size_t)v + 16;
+  return 0;
+}
+
+/* DecoderState::try_process_next, lzma.rs:401-417: process_next_inner(update = false) (lzma.rs:278-393) on a copy of the range coder
+ * over `buf` -- nothing of the decoder or the output changes; what can fail is a read beyond `buf` and the matched literal's
+ * last_n (decode_literal, lzma.rs:543-545).  The marker test, the LRU / state updates and every append are inside `if update`.
+ * Returns 0 = Ok, 1 = Err. */
+static int dstate_try_process_next(const dstate_t *s, const lzbuf_t *output, const uint8_t *buf, size_t n, uint32_t range,
+                                   uint32_t code) {
+  reader_t temp = {buf, 0, n};
+  rc_t rc;
+  err_t scratch;
+  size_t pos_state = (size_t)(output->len & (((uint64_t)1 << s->lzma_props.pb) - 1));
+  size_t len;
+  int bit;
+  rc.stream = &temp;
+  rc.range = range;
+  rc.code = code;
+  memset(&scratch, 0, sizeof scratch);
+  bit = rc_peek_bit(&rc, s->is_match[(s->state << 4) + pos_state]);
+  if (bit < 0) return 1;
+  if (!bit) { /* decode_literal, lzma.rs:526-561, update = false */
+    size_t prev_byte = lzbuf_last_or(output, 0);
+    size_t result = 1;
+    size_t lit_state = ((size_t)(output->len & (((uint64_t)1 << s->lzma_props.lp) - 1)) << s->lzma_props.lc) +
+                       (prev_byte >> (8 - s->lzma_props.lc));
+    const uint16_t *probs = s->literal_probs + lit_state * 0x300;
+    if (s->state >= 7) {
+      uint8_t mb = 0;
+      size_t match_byte;
+      if (lzbuf_last_n(output, s->rep[0] + 1, &mb, &scratch)) return 1;
+      match_byte = mb;
+      while (result < 0x100) {
+        size_t match_bit = (match_byte >> 7) & 1;
+        match_byte <<= 1;
+        bit = rc_peek_bit(&rc, probs[((1 + match_bit) << 8) + result]);
+        if (bit < 0) return 1;
+        result = (result << 1) ^ (size_t)bit;
+        if (match_bit != (size_t)bit) break;
+      }
+    }
+    while (result < 0x100) {
+      bit = rc_peek_bit(&rc, probs[result]);
+      if (bit < 0) return 1;
+      result = (result << 1) ^ (size_t)bit;
+    }
+    return 0;
+  }
+  bit = rc_peek_bit(&rc, s->is_rep[s->state]);
+  if (bit < 0) return 1;
+  if (bit) {
+    bit = rc_peek_bit(&rc, s->is_rep_g0[s->state]);
+    if (bit < 0) return 1;
+    if (!bit) {
+      bit = rc_peek_bit(&rc, s->is_rep_0long[(s->state << 4) + pos_state]);
+      if (bit < 0) return 1;
+      if (!bit) return 0; /* short rep */
+    } else {
+      bit = rc_peek_bit(&rc, s->is_rep_g1[s->state]);
+      if (bit < 0) return 1;
+      if (bit) {
+        bit = rc_peek_bit(&rc, s->is_rep_g2[s->state]);
+        if (bit < 0) return 1;
+      }
+    }
+    if (lendec_peek(&s->rep_len_decoder, &rc, pos_state, &len)) return 1;
+  } else { /* new distance: decode_distance, lzma.rs:563-592, update = false */
+    size_t len_state, pos_slot, num_direct_bits;
+    uint64_t result;
+    uint32_t v;
+    if (lendec_peek(&s->len_decoder, &rc, pos_state, &len)) return 1;
+    len_state = len > 3 ? 3 : len;
+    if (rc_peek_bit_tree(&rc, 6, s->pos_slot_decoder[len_state], &v)) return 1;
+    pos_slot = v;
+    if (pos_slot >= 4) {
+      num_direct_bits = (pos_slot >> 1) - 1;
+      result = (uint64_t)(2 ^ (pos_slot & 1)) << num_direct_bits;
+      if (pos_slot < 14) {
+        if (rc_peek_reverse_bit_tree(&rc, (unsigned)num_direct_bits, s->pos_decoders, (size_t)(result - pos_slot), &v)) return 1;
+      } else {
+        if (rc_get(&rc, (unsigned)(num_direct_bits - 4), &v)) return 1;
+        if (rc_peek_reverse_bit_tree(&rc, 4, s->align_decoder, 0, &v)) return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+#define ORC_MAX_REQUIRED_INPUT 20 /* lzma.rs:13 */
+enum { ORC_MODE_PARTIAL = 0, ORC_MODE_FINISH = 1 };
+
+/* DecoderState::process_mode, lzma.rs:435-524, with the partial input buffer of lzma.rs:166-168 (`partial`, `*partial_pos`).
+ * Returns 0 or the error kind. */
+static int dstate_process_mode(dstate_t *s, lzbuf_t *output, rc_t *rc, int mode, uint8_t *partial, size_t *partial_pos, err_t *e) {
+  for (;;) {
+    if (s->unpacked_is_some) {
+      if (output->len >= s->unpacked_size) break;
+    } else if (mode == ORC_MODE_PARTIAL ? (rd_is_eof(rc->stream) && *partial_pos == 0)
+                                        : (rc_is_finished_ok(rc) && *partial_pos == 0)) {
+      break;
+    }
+    if (*partial_pos > 0) {
+      uint8_t tmp[ORC_MAX_REQUIRED_INPUT];
+      reader_t tmp_reader;
+      rc_t tmp_rc;
+      size_t take, new_len;
+      int st;
+      /* read_partial_input_buf, lzma.rs:420-433: as much as there is, up to the buffer's end */
+      take = rc->stream->end - rc->stream->pos;
+      if (take > ORC_MAX_REQUIRED_INPUT - *partial_pos) take = ORC_MAX_REQUIRED_INPUT - *partial_pos;
+      memcpy(partial + *partial_pos, rc->stream->p + rc->stream->pos, take);
+      rc->stream->pos += take;
+      *partial_pos += take;
+      memcpy(tmp, partial, sizeof tmp);
+      if (mode == ORC_MODE_PARTIAL && *partial_pos < ORC_MAX_REQUIRED_INPUT &&
+          dstate_try_process_next(s, output, tmp, *partial_pos, rc->range, rc->code))
+        return 0; /* need more data */
+      tmp_reader.p = tmp;
+      tmp_reader.pos = 0;
+      tmp_reader.end = *partial_pos;
+      tmp_rc.stream = &tmp_reader;
+      tmp_rc.range = rc->range;
+      tmp_rc.code = rc->code;
+      st = dstate_process_next(s, output, &tmp_rc, e);
+      if (st == ST_ERROR) return e->kind;
+      rc->range = tmp_rc.range;
+      rc->code = tmp_rc.code;
+      new_len = *partial_pos - tmp_reader.pos;
+      memcpy(partial, tmp + tmp_reader.pos, new_len);
+      *partial_pos = new_len;
+      if (st == ST_FINISHED) break;
+    } else {
+      const uint8_t *buf = rc->stream->p + rc->stream->pos;
+      size_t n = rc->stream->end - rc->stream->pos;
+      int st;
+      if (mode == ORC_MODE_PARTIAL && n < ORC_MAX_REQUIRED_INPUT && dstate_try_process_next(s, output, buf, n, rc->range, rc->code)) {
+        /* return self.read_partial_input_buf(rangecoder) */
+        size_t take = n > ORC_MAX_REQUIRED_INPUT ? ORC_MAX_REQUIRED_INPUT : n;
+        memcpy(partial, buf, take);
+        rc->stream->pos += take;
+        *partial_pos = take;
+        return 0;
+      }
+      st = dstate_process_next(s, output, rc, e);
+      if (st == ST_ERROR) return e->kind;
+      if (st == ST_FINISHED) break;
+    }
+  }
+  if (s->unpacked_is_some && mode == ORC_MODE_FINISH && s->unpacked_size != output->len)
+    return fail(e, ORC_LZMA_ERROR, "Expected unpacked size of %llu but decompressed to %llu", (unsigned long long)s->unpacked_size,
+                (unsigned long long)output->len);
+  return 0;
+}
+
+#define ORC_MAX_TMP_LEN 18 /* stream.rs:9-24: MAX_HEADER_LEN (5 + 8) + START_BYTES (5) */
+
+struct orc_stream {
+  orc_options options;
+  int allow_incomplete;
+  uint8_t tmp[ORC_MAX_TMP_LEN]; /* Stream.tmp */
+  size_t tmp_pos;
+  int state; /* 0: State::Header(W), 1: State::Data(RunState), 2: None (a write failed, or finished) */
+  sink_t sink; /* W = Vec<u8> */
+  dstate_t decoder; /* RunState */
+  uint32_t range, code;
+  lzbuf_t output;
+  uint8_t partial[ORC_MAX_REQUIRED_INPUT]; /* DecoderState.partial_input_buf */
+  size_t partial_pos;
+};
+
+/* Stream::new_with_options, stream.rs:88-101 */
+orc_stream *orc_stream_new(const orc_options *opt, int allow_incomplete) {
+  orc_stream *s = (orc_stream *)calloc(1, sizeof *s);
+  if (opt) s->options = *opt;
+  s->allow_incomplete = allow_incomplete;
+  return s;
+}
+
+/* Stream::read_header, stream.rs:153-189.  Returns the next state (0 Header / 1 Data), or -1 with *e set (fatal). */
+static int stream_read_header(orc_stream *s, reader_t *input, err_t *e) {
+  params_t params;
+  err_t he;
+  rc_t rc;
+  memset(&he, 0, sizeof he);
+  if (read_header(input, &s->options, &params, &he)) {
+    if (he.kind == ORC_HEADER_TOO_SHORT) return 0; /* need more data, try again later */
+    *e = he;
+    return -1;
+  }
+  if (rc_new(&rc, input)) return 0; /* header read, range coder start not there yet: Header again (the decoder made here is dropped) */
+  dstate_new(&s->decoder, params.properties, params.unpacked_is_some, params.unpacked_size);
+  memset(&s->output, 0, sizeof s->output);
+  s->output.is_accum = 0;
+  s->output.stream = &s->sink;
+  s->output.dict_size = params.dict_size;
+  s->output.memlimit = s->options.memlimit_is_some ? s->options.memlimit : UINT64_MAX;
+  s->range = rc.range;
+  s->code = rc.code;
+  s->partial_pos = 0;
+  return 1;
+}
+
+/* Stream::read_data, stream.rs:192-207: process_stream; an error becomes io::Error::new(Other, format!("{:?}", error)) (stream.rs:343-347) */
+static int stream_read_data(orc_stream *s, reader_t *input, err_t *e) {
+  rc_t rc;
+  err_t de;
+  memset(&de, 0, sizeof de);
+  rc.stream = input;
+  rc.range = s->range;
+  rc.code = s->code;
+  if (dstate_process_mode(&s->decoder, &s->output, &rc, ORC_MODE_PARTIAL, s->partial, &s->partial_pos, &de)) {
+    /* Debug of error::Error (derive): LzmaError("...") / XzError("...") / IoError(..) -- only LzmaError can come out of Partial mode on
+     * a byte slice; the text after the Display prefix is the variant's String */
+    const char *m = strchr(de.msg, ':');
+    m = m ? m + 2 : de.msg;
+    e->kind = ORC_IO_ERROR;
+    snprintf(e->msg, sizeof e->msg, "%s(\"%.360s\")", de.kind == ORC_LZMA_ERROR ? "LzmaError" : de.kind == ORC_XZ_ERROR ? "XzError" : "IoError", m);
+    return 1;
+  }
+  s->range = rc.range;
+  s->code = rc.code;
+  return 0;
+}
+
+/* <Stream as io::Write>::write, stream.rs:223-326.  *consumed = Ok(n); returns 0, or 1 with e = the io::Error (Display text in e->msg
+ * WITHOUT a prefix: this is an io::Error, not an error::Error). */
+static int stream_write(orc_stream *s, const uint8_t *data, size_t len, size_t *consumed, err_t *e) {
+  reader_t input = {data, 0, len};
+  if (s->state != 2) {
+    int st = s->state;
+    s->state = 2; /* self.state.take() */
+    if (st == 0) {
+      int res;
+      if (s->tmp_pos > 0) {
+        size_t take = len < ORC_MAX_TMP_LEN - s->tmp_pos ? len : ORC_MAX_TMP_LEN - s->tmp_pos;
+        reader_t tmp_input;
+        memcpy(s->tmp + s->tmp_pos, data, take);
+        input.pos = take;
+        s->tmp_pos += take;
+        tmp_input.p = s->tmp;
+        tmp_input.pos = 0;
+        tmp_input.end = s->tmp_pos;
+        res = stream_read_header(s, &tmp_input, e);
+        if (res == 1) { /* discard the bytes up to position */
+          size_t new_len = s->tmp_pos - tmp_input.pos;
+          memmove(s->tmp, s->tmp + tmp_input.pos, new_len);
+          s->tmp_pos = new_len;
+        }
+      } else {
+        res = stream_read_header(s, &input, e);
+      }
+      if (res == 0) {
+        if (s->tmp_pos == 0) { /* reset the cursor because we may have partial reads */
+          size_t take = len < ORC_MAX_TMP_LEN ? len : ORC_MAX_TMP_LEN;
+          memcpy(s->tmp, data, take);
+          input.pos = take;
+          s->tmp_pos = take;
+        }
+        st = 0;
+      } else if (res == 1) {
+        st = 1;
+      } else { /* IoError(e) | HeaderTooShort(e) => e; LzmaError(s) | XzError(s) => io::Error::new(Other, s) */
+        const char *m = strchr(e->msg, ':');
+        char plain[384];
+        snprintf(plain, sizeof plain, "%s", m ? m + 2 : e->msg);
+        memcpy(e->msg, plain, sizeof plain);
+        e->kind = ORC_IO_ERROR;
+        return 1;
+      }
+    } else {
+      if (s->tmp_pos > 0) {
+        reader_t tmp_input = {s->tmp, 0, s->tmp_pos};
+        if (stream_read_data(s, &tmp_input, e)) return 1;
+        s->tmp_pos = 0;
+      }
+      if (stream_read_data(s, &input, e)) return 1;
+      st = 1;
+    }
+    s->state = st;
+  }
+  *consumed = input.pos;
+  return 0;
+}
+
+/* io::Write::write_all (std): write until everything is taken; Ok(0) from write is ErrorKind::WriteZero, "failed to write whole buffer".
+ * Returns 0 or ORC_IO_ERROR; msg (384 bytes) = the io::Error's Display text. */
+int orc_stream_write_all(orc_stream *s, const uint8_t *data, size_t len, char *msg) {
+  err_t e;
+  memset(&e, 0, sizeof e);
+  while (len > 0) {
+    size_t n = 0;
+    if (stream_write(s, data, len, &n, &e)) {
+      memcpy(msg, e.msg, sizeof e.msg);
+      return ORC_IO_ERROR;
+    }
+    if (n == 0) {
+      snprintf(msg, 384, "failed to write whole buffer");
+      return ORC_IO_ERROR;
+    }
+    data += n;
+    len -= n;
+  }
+  msg[0] = 0;
+  return 0;
+}
+
+/* Stream::get_output, stream.rs:104-109: what the sink holds so far */
+size_t orc_stream_output(const orc_stream *s, const uint8_t **p) {
+  *p = s->sink.data;
+  return s->sink.len;
+}
+
+/* Stream::finish, stream.rs:119-150; frees the stream.  res->out = what the sink holds (Ok: the whole output; Err: the reference drops W). */
+int orc_stream_finish(orc_stream *s, orc_result *res) {
+  err_t e;
+  reader_t none = {NULL, 0, 0};
+  memset(&e, 0, sizeof e);
+  if (s->state == 0) {
+    if (s->tmp_pos > 0) fail(&e, ORC_LZMA_ERROR, "failed to read header");
+  } else if (s->state == 1) {
+    int r = 0;
+    if (!s->allow_incomplete) { /* one last time with (what is left in tmp as) input: the end-of-stream checks */
+      reader_t stream = {s->tmp, 0, s->tmp_pos};
+      rc_t rc;
+      rc.stream = &stream;
+      rc.range = s->range;
+      rc.code = s->code;
+      r = dstate_process_mode(&s->decoder, &s->output, &rc, ORC_MODE_FINISH, s->partial, &s->partial_pos, &e);
+    }
+    if (!r) lzbuf_finish(&s->output);
+  } else {
+    fail(&e, ORC_LZMA_ERROR, "can't finish stream because of previous write error");
+  }
+  if (s->state == 1 || s->output.buf) {
+    free(s->output.buf);
+    dstate_free(&s->decoder);
+  }
+  finish_result(res, &e, &s->sink, &none);
+  free(s);
+  return res->kind;
+}
+
+/* ------------------------------------------------------------------ */
 /* cpu_baseline helper                                                 */
 /* ------------------------------------------------------------------ */
 

@@ -141,3 +141,38 @@ def crc32(data):
 
 def crc64(data):
     return lib().orc_crc64(data, len(data))
+
+
+class Stream:
+    """The oracle's restatement of lzma_rs::decompress::Stream over a Vec<u8> sink (src/decode/stream.rs): write_all() raises
+    StreamWriteError(text of the io::Error) like Write::write_all returns Err; finish() -> OracleResult."""
+
+    class WriteError(Exception):
+        pass
+
+    def __init__(self, unpacked_size_mode=READ_FROM_HEADER, provided=None, memlimit=None, allow_incomplete=False):
+        L = lib()
+        L.orc_stream_new.restype = ctypes.c_void_p
+        L.orc_stream_new.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_stream_write_all.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.orc_stream_output.restype = ctypes.c_size_t
+        L.orc_stream_output.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))]
+        L.orc_stream_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        o = _opts(unpacked_size_mode, provided, memlimit)
+        self._h = L.orc_stream_new(ctypes.byref(o), 1 if allow_incomplete else 0)
+
+    def write_all(self, data):
+        msg = ctypes.create_string_buffer(384)
+        if lib().orc_stream_write_all(self._h, bytes(data), len(data), msg) != 0:
+            raise Stream.WriteError(msg.value.decode("utf-8", "replace"))
+
+    def get_output(self):
+        p = ctypes.POINTER(ctypes.c_uint8)()
+        n = lib().orc_stream_output(self._h, ctypes.byref(p))
+        return ctypes.string_at(p, n) if n else b""
+
+    def finish(self):
+        res = _Result()
+        lib().orc_stream_finish(self._h, ctypes.byref(res))
+        self._h = None
+        return _take(res)

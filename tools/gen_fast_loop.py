@@ -246,7 +246,9 @@ EXIT = dict(DONE_SIZE=0, DONE_FIN=1, INPUT_EOF=2, MARKER=3, LIMIT=4, LZ_SLOW=5, 
 # running a symbol into the end of the view.  Costs the ordinary loop two scalar instructions per window refill (set_guards).
 FEED = os.environ.get("MILZMA_GEN_FEED", "1") == "1"   # (0: the loop without it -- A/B of what its few scalar instructions and the shift of the code behind them cost)
 FEED_BIT = 5
-FEED_MARGIN = 32
+FEED_GUARD = 1 << FEED_BIT   # symbol tops look closer (the slow way round) once fewer than this many bytes lie beyond the reader's window
+FEED_MARGIN = 20             # ... and leave when fewer than this many bytes of the view are left: the most one symbol can read (the reference's
+                             # MAX_REQUIRED_INPUT, lzma.rs:13 -- its streaming mode decodes a symbol without a trial run on exactly this condition)
 # ---- operands -------------------------------------------------------------------------------------------
 OPS_INOUT_S = ["range", "code", "off", "lim", "wbase", "len", "state", "rep0", "rep1", "rep2", "rep3", "prev",
                "mb", "pend_n", "pend_pos", "cur_row", "mlen", "exitcode", "prof_wm", "prof_nm", "prof_wc", "prof_nc", "tbl_ready"]
@@ -886,10 +888,10 @@ class Gen:
         if EOFWRAP:
             # every symbol looks closer once the reader is at EOF (lim = -1) -- with FEED: from the view's last window on (lim = 0, -1)
             if FEED:
-                assert (1 << FEED_BIT) == FEED_MARGIN
-                e("s_and_b32 {gdist}, {lc8}, %d" % FEED_MARGIN)    # (gdist: set below) 0, or FEED_MARGIN when the view will be continued
+                assert FEED_GUARD >= FEED_MARGIN
+                e("s_and_b32 {gdist}, {lc8}, %d" % FEED_GUARD)     # (gdist: set below) 0, or FEED_GUARD when the view will be continued
                 e("s_add_u32 {t}, {lim}, 1", t=t)
-                e("s_cmp_gt_u32 {t}, {gdist}", t=t)               # lim >= FEED_MARGIN: no symbol that starts in this window can reach the view's end
+                e("s_cmp_gt_u32 {t}, {gdist}", t=t)               # lim >= FEED_GUARD: no symbol that starts in this window can reach the view's end
             else:
                 e("s_cmp_lg_u32 {lim}, -1")                     # -1: the reader IS at EOF
         elif OFFBIAS:
