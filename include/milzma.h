@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MILZMA_ABI_VERSION 4
+#define MILZMA_ABI_VERSION 5
 
 /* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
 enum {
@@ -46,6 +46,9 @@ enum {
 #define MILZMA_KIND_RAW_LZMA 0u /* LzmaDecoder::decompress: input starts at the range coder's first byte */
 #define MILZMA_KIND_LZMA2 1u    /* Lzma2Decoder::decompress: input starts at an LZMA2 status byte          */
 #define MILZMA_KIND_LAST_VIEW 0x80u /* or-ed into `kind` in a MILZMA_DECODE_FEED call: this unit's view ends where its stream ends */
+#define MILZMA_KIND_HOLD 0x40u  /* ... in a RESUME | FEED call: this parked unit stays parked (nothing new for it); its result is kept */
+#define MILZMA_KIND_START 0x20u /* ... in a RESUME | FEED call: this unit is new -- it starts now, in the place i of the batch, beside the
+                                   units that resume (continuous batching: the streams of a batch need not begin together) */
 
 #define MILZMA_SIZE_UNKNOWN UINT64_MAX /* unpacked_size: Option::None => end-of-stream marker mode */
 #define MILZMA_NO_LIMIT UINT64_MAX     /* memlimit: Option::None                                    */
@@ -190,6 +193,9 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *                         size / LZMA2 end byte met inside a view ends the unit as usual.  Asm-kernel classes only (a context under
  *                         MILZMA_KERNEL / MILZMA_SPILL = generic refuses the flag); LZMA2 units run with a literal-row slab (a
  *                         property switch can be followed without decoding again from a start that is no longer there).
+ *                         A batch under FEED need not begin together: in a RESUME | FEED call a unit marked MILZMA_KIND_START starts
+ *                         fresh in its place of the batch (which must hold no parked unit) beside the units that resume -- such a call
+ *                         may even be the first of its batch --, and a parked unit marked MILZMA_KIND_HOLD is left parked.
  * Parked states live until the next decode call on the context that is not a RESUME. */
 #define MILZMA_DECODE_GROW 1u
 #define MILZMA_DECODE_RESUME 2u
@@ -235,13 +241,13 @@ enum {
   MILZMA_USE_PROVIDED = 2
 };
 
-/* decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only. */
+/* decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only (milzma_streams_*). */
 typedef struct milzma_options {
   int32_t unpacked_size_mode;
   int32_t provided_is_some;
   uint64_t provided;
   int32_t memlimit_is_some;
-  int32_t reserved;
+  int32_t allow_incomplete; /* Options.allow_incomplete (options.rs:16-19): finish() of a stream whose input ends early is a success */
   uint64_t memlimit;
 } milzma_options;
 
@@ -392,6 +398,42 @@ uint32_t milzma_crc32(const uint8_t *p, size_t n);
 uint64_t milzma_crc64(const uint8_t *p, size_t n);
 
 uint32_t milzma_abi_version(void);
+
+/* ---- push-mode decoding: lzma_rs::decompress::Stream (feature `stream`, src/decode/stream.rs) for a batch of streams -----------------
+ * The crate's Stream<W> is an io::Write: the compressed .lzma bytes are written to it piece by piece, finish() hands the sink back.
+ * A milzma_streams is n of them over one GPU (a context of its own behind `ctx`'s device): a write call appends bytes to any of the
+ * streams and runs ONE launch in which every stream that got bytes takes another turn (fed input, MILZMA_DECODE_FEED: streams whose
+ * header has just become complete start in that launch, the others resume where they parked).  Output stays on the device until finish.
+ *   milzma_streams_open    n x Stream::new_with_options (stream.rs:88-101); options: n entries (unpacked_size mode, memlimit,
+ *                          allow_incomplete) or NULL for Options::default().
+ *   milzma_streams_write   io::Write::write_all (over Stream::write, stream.rs:223-326) for k of the streams: data[j] / len[j] go to
+ *                          stream idx[j] (a stream at most once per call).  status[j] (optional): MILZMA_OK, or MILZMA_IO_ERROR when that
+ *                          write_all returns Err -- milzma_streams_write_error(s, idx[j]) is the io::Error's text: a fatal header error
+ *                          ("LZMA header invalid properties: 255 must be < 225"), a decode error in the crate's Debug form
+ *                          (`LzmaError("LZ distance 5 is beyond output size 3")`, stream.rs:343-347), or "failed to write whole buffer"
+ *                          (ErrorKind::WriteZero: bytes behind a stream whose declared size is reached; the stream itself is intact,
+ *                          tests/lzma.rs:71-87).  After a failed write (other than WriteZero) the stream takes further writes without
+ *                          doing anything, as the reference does, and its finish() fails.  Returns MILZMA_INFRA_ERROR only for
+ *                          infrastructure failures (milzma_streams_last_error).
+ *   milzma_streams_finish  Stream::finish (stream.rs:119-150) for every stream: outs[i] as from milzma_lzma_decompress -- kind / msg of
+ *                          the crate's Result (header incomplete: "lzma error: failed to read header"; input ends early: "io error:
+ *                          failed to fill whole buffer", unless allow_incomplete, which hands over everything decoded so far; after a
+ *                          failed write: "lzma error: can't finish stream because of previous write error"), data = what the sink holds.
+ *                          Once; afterwards only milzma_streams_close (which may also be called without finish).
+ * Differences from the crate, all in WHEN and not in WHAT: the crate decodes a symbol as soon as 20 bytes are at hand OR a trial run
+ * shows it complete within fewer; here the second case waits for the next write (or finish).  So an error inside the last 19 bytes of
+ * everything written so far is reported one call later than by the crate, and Stream::get_output is not offered (the sink's contents
+ * between calls depend on exactly that).  And nothing is decoded BEHIND AN END MARKER: the crate's loop merely leaves at the marker, so
+ * bytes written to the stream in a later call are decoded on from the marker's state (here: WriteZero), and a finish() that finds a
+ * provided size not reached trips over the marker's distance ("Match distance 4294967296 is beyond dictionary size ..."; here: the
+ * one-shot call's "Expected unpacked size of {} but decompressed to {}"). */
+typedef struct milzma_streams milzma_streams;
+int milzma_streams_open(milzma_ctx *ctx, uint32_t n, const milzma_options *options, milzma_streams **out);
+int milzma_streams_write(milzma_streams *s, uint32_t k, const uint32_t *idx, const void *const *data, const size_t *len, int32_t *status);
+const char *milzma_streams_write_error(const milzma_streams *s, uint32_t stream);
+int milzma_streams_finish(milzma_streams *s, milzma_output *outs);
+void milzma_streams_close(milzma_streams *s);
+const char *milzma_streams_last_error(const milzma_streams *s);
 
 #ifdef __cplusplus
 }

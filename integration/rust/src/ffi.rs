@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_float, c_int, c_void};
 
-pub const MILZMA_ABI_VERSION: u32 = 4;
+pub const MILZMA_ABI_VERSION: u32 = 5;
 
 // error kinds: error::Error variants (src/error.rs:8-17)
 pub const MILZMA_OK: c_int = 0;
@@ -18,6 +18,10 @@ pub const MILZMA_KIND_RAW_LZMA: u8 = 0;
 pub const MILZMA_KIND_LZMA2: u8 = 1;
 /// or-ed into `milzma_unit.kind` in a `MILZMA_DECODE_FEED` call: this unit's view ends where its stream ends
 pub const MILZMA_KIND_LAST_VIEW: u8 = 0x80;
+/// ... in a RESUME | FEED call: this parked unit stays parked (nothing new for it)
+pub const MILZMA_KIND_HOLD: u8 = 0x40;
+/// ... in a RESUME | FEED call: this unit is new and starts now, beside the units that resume
+pub const MILZMA_KIND_START: u8 = 0x20;
 pub const MILZMA_SIZE_UNKNOWN: u64 = u64::MAX;
 pub const MILZMA_NO_LIMIT: u64 = u64::MAX;
 pub const MILZMA_MAX_UNIT_BYTES: u64 = 0xFFFF_FF00;
@@ -71,7 +75,7 @@ pub struct milzma_result {
     pub err_b: u64,
 }
 
-/// decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only.
+/// decompress::Options (src/decode/options.rs:3-20); allow_incomplete is stream-API only (milzma_streams_*).
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct milzma_options {
@@ -79,7 +83,7 @@ pub struct milzma_options {
     pub provided_is_some: i32,
     pub provided: u64,
     pub memlimit_is_some: i32,
-    pub reserved: i32,
+    pub allow_incomplete: i32,
     pub memlimit: u64,
 }
 
@@ -95,6 +99,12 @@ pub struct milzma_output {
 
 #[repr(C)]
 pub struct milzma_ctx {
+    _opaque: [u8; 0],
+}
+
+/// n push-mode .lzma decoders on one GPU (lzma_rs::decompress::Stream for a batch)
+#[repr(C)]
+pub struct milzma_streams {
     _opaque: [u8; 0],
 }
 
@@ -311,4 +321,18 @@ extern "C" {
         in_lens: *const usize,
         outs: *mut milzma_output,
     ) -> c_int;
+    // push-mode decoding: Stream (feature `stream`) for a batch of streams
+    pub fn milzma_streams_open(ctx: *mut milzma_ctx, n: u32, options: *const milzma_options, out: *mut *mut milzma_streams) -> c_int;
+    pub fn milzma_streams_write(
+        s: *mut milzma_streams,
+        k: u32,
+        idx: *const u32,
+        data: *const *const c_void,
+        len: *const usize,
+        status: *mut i32,
+    ) -> c_int;
+    pub fn milzma_streams_write_error(s: *const milzma_streams, stream: u32) -> *const c_char;
+    pub fn milzma_streams_finish(s: *mut milzma_streams, outs: *mut milzma_output) -> c_int;
+    pub fn milzma_streams_close(s: *mut milzma_streams);
+    pub fn milzma_streams_last_error(s: *const milzma_streams) -> *const c_char;
 }

@@ -240,7 +240,7 @@ fn c_options(o: &decompress::Options) -> ffi::milzma_options {
         provided_is_some: provided.is_some() as i32,
         provided: provided.unwrap_or(0),
         memlimit_is_some: o.memlimit.is_some() as i32,
-        reserved: 0,
+        allow_incomplete: o.allow_incomplete as i32,
         memlimit: o.memlimit.unwrap_or(0) as u64,
     }
 }
@@ -519,6 +519,126 @@ pub fn xz_decompress_batches_pipelined<'f>(
         }
     }
     Ok(())
+}
+
+/// `lzma_rs::decompress::Stream` (feature `stream`, src/decode/stream.rs) for a BATCH of streams on one GPU: the compressed `.lzma`
+/// bytes of each stream are written piece by piece, `finish` hands every stream's verdict and output over.  One `write` call gives any
+/// number of the streams another turn in ONE launch (fed input, `MILZMA_DECODE_FEED`: streams start when their header is complete,
+/// resume where they parked, or sit the call out).  Where this differs from the crate -- WHEN an error inside the last 19 bytes written
+/// so far is reported, and that nothing is decoded behind an end marker -- is spelled out in include/milzma.h.
+pub struct Streams {
+    raw: *mut ffi::milzma_streams,
+    n: usize,
+}
+
+impl Streams {
+    /// n x `Stream::new_with_options` (stream.rs:88-101); `options`: one per stream, or empty for `Options::default()`.
+    pub fn new(ctx: &Context, n: usize, options: &[decompress::Options]) -> error::Result<Streams> {
+        assert!(options.is_empty() || options.len() == n);
+        let copts: Vec<ffi::milzma_options> = options.iter().map(c_options).collect();
+        let mut raw = ptr::null_mut();
+        let rc = unsafe { ffi::milzma_streams_open(ctx.raw, n as u32, if copts.is_empty() { ptr::null() } else { copts.as_ptr() }, &mut raw) };
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_streams_open", unsafe { ffi::milzma_last_error(ctx.raw) }));
+        }
+        Ok(Streams { raw, n })
+    }
+
+    /// `io::Write::write_all` for each `(stream, bytes)` of `pieces` (a stream at most once per call): what comes back is one
+    /// `io::Result` per piece, `Err` with the text the crate's `write_all` error displays (stream.rs:291-299, :343-347).
+    pub fn write(&mut self, pieces: &[(usize, &[u8])]) -> error::Result<Vec<io::Result<()>>> {
+        let idx: Vec<u32> = pieces.iter().map(|p| p.0 as u32).collect();
+        let data: Vec<*const std::os::raw::c_void> = pieces.iter().map(|p| p.1.as_ptr() as *const _).collect();
+        let len: Vec<usize> = pieces.iter().map(|p| p.1.len()).collect();
+        let mut status = vec![0i32; pieces.len()];
+        let rc = unsafe { ffi::milzma_streams_write(self.raw, pieces.len() as u32, idx.as_ptr(), data.as_ptr(), len.as_ptr(), status.as_mut_ptr()) };
+        if rc != ffi::MILZMA_OK {
+            return Err(infra("milzma_streams_write", unsafe { ffi::milzma_streams_last_error(self.raw) }));
+        }
+        Ok(status
+            .iter()
+            .zip(&idx)
+            .map(|(&st, &i)| {
+                if st == ffi::MILZMA_OK {
+                    return Ok(());
+                }
+                let text = unsafe { CStr::from_ptr(ffi::milzma_streams_write_error(self.raw, i)) }.to_string_lossy().into_owned();
+                let kind = if text == "failed to write whole buffer" { io::ErrorKind::WriteZero } else { io::ErrorKind::Other };
+                Err(io::Error::new(kind, text))
+            })
+            .collect())
+    }
+
+    /// `Stream::finish` (stream.rs:119-150) for every stream; consumes the batch.
+    pub fn finish(self) -> Vec<Decoded> {
+        let mut outs: Vec<ffi::milzma_output> = (0..self.n).map(|_| empty_output()).collect();
+        let rc = unsafe { ffi::milzma_streams_finish(self.raw, outs.as_mut_ptr()) };
+        let raw = self.raw;
+        collect(rc, || infra("milzma_streams_finish", unsafe { ffi::milzma_streams_last_error(raw) }), outs)
+        // (Drop closes the batch)
+    }
+}
+
+impl Drop for Streams {
+    fn drop(&mut self) {
+        unsafe { ffi::milzma_streams_close(self.raw) }
+    }
+}
+
+/// ONE push-mode decoder with the crate's own shape -- `Stream::new(output)`, `io::Write`, `finish() -> Result<W>` -- for code that is
+/// written against `lzma_rs::decompress::Stream<W>`.  (A batch of one stream leaves the GPU idle: `Streams` is the form to use when many
+/// streams arrive at once.)  The output reaches `W` at `finish`; `get_output` shows the sink as it is.
+pub struct Stream<W: io::Write> {
+    inner: Option<Streams>,
+    output: Option<W>,
+}
+
+impl<W: io::Write> Stream<W> {
+    pub fn new(output: W) -> error::Result<Self> {
+        Self::new_with_options(&decompress::Options::default(), output)
+    }
+
+    pub fn new_with_options(options: &decompress::Options, output: W) -> error::Result<Self> {
+        let inner = with_default_ctx(|ctx| Streams::new(ctx, 1, std::slice::from_ref(options)))?;
+        Ok(Stream { inner: Some(inner), output: Some(output) })
+    }
+
+    pub fn get_output(&self) -> Option<&W> {
+        self.output.as_ref()
+    }
+
+    pub fn get_output_mut(&mut self) -> Option<&mut W> {
+        self.output.as_mut()
+    }
+
+    /// Stream::finish (stream.rs:119-150): the sink with everything decoded, or the stream's error.
+    pub fn finish(mut self) -> error::Result<W> {
+        let inner = self.inner.take().expect("finish is called once");
+        let mut output = self.output.take().expect("finish is called once");
+        let mut done = inner.finish();
+        let d = done.pop().expect("one stream");
+        d.result?;
+        output.write_all(&d.data)?;
+        output.flush()?;
+        Ok(output)
+    }
+}
+
+impl<W: io::Write> io::Write for Stream<W> {
+    fn write(&mut self, data: &[u8]) -> io::Result<usize> {
+        let inner = self.inner.as_mut().expect("not finished");
+        let mut r = inner
+            .write(&[(0, data)])
+            .map_err(|e| io::Error::new(io::ErrorKind::Other, e.to_string()))?;
+        r.pop().expect("one piece").map(|_| data.len())
+    }
+
+    fn flush(&mut self) -> io::Result<()> {
+        match self.output.as_mut() {
+            Some(w) => w.flush(),
+            None => Ok(()),
+        }
+    }
 }
 
 #[cfg(test)]

@@ -107,7 +107,7 @@ class Options:
     def __init__(self, unpacked_size=None, memlimit=None, allow_incomplete=False):
         self.unpacked_size = unpacked_size or UnpackedSize.ReadFromHeader()
         self.memlimit = memlimit
-        self.allow_incomplete = allow_incomplete  # stream API only; no effect here (as in the crate)
+        self.allow_incomplete = allow_incomplete  # stream API only (Streams); no effect on the one-shot calls (as in the crate)
 
 
 # ---- ctypes mirror of the ABI structs --------------------------------------------------------
@@ -129,7 +129,7 @@ class Result(ctypes.Structure):
 class _COptions(ctypes.Structure):
     _fields_ = [("unpacked_size_mode", ctypes.c_int32), ("provided_is_some", ctypes.c_int32),
                 ("provided", ctypes.c_uint64), ("memlimit_is_some", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("memlimit", ctypes.c_uint64)]
+                ("allow_incomplete", ctypes.c_int32), ("memlimit", ctypes.c_uint64)]
 
 
 class _COutput(ctypes.Structure):
@@ -152,6 +152,8 @@ EXPORTS = [
     "milzma_batch_wait",
     "milzma_decode_units_ex", "milzma_move_units", "milzma_pool_trim",
     "milzma_multi_decode_units_rooted", "milzma_multi_last_transfer_ms",
+    "milzma_streams_open", "milzma_streams_write", "milzma_streams_write_error", "milzma_streams_finish", "milzma_streams_close",
+    "milzma_streams_last_error",
 ]
 
 _lib = None
@@ -236,6 +238,14 @@ def lib():
     L.milzma_crc32.argtypes = [vp, sz]
     L.milzma_crc64.restype = u64
     L.milzma_crc64.argtypes = [vp, sz]
+    L.milzma_streams_open.argtypes = [vp, u32, ctypes.POINTER(_COptions), ctypes.POINTER(vp)]
+    L.milzma_streams_write.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int32)]
+    L.milzma_streams_write_error.restype = ctypes.c_char_p
+    L.milzma_streams_write_error.argtypes = [vp, u32]
+    L.milzma_streams_finish.argtypes = [vp, ctypes.POINTER(_COutput)]
+    L.milzma_streams_close.argtypes = [vp]
+    L.milzma_streams_last_error.restype = ctypes.c_char_p
+    L.milzma_streams_last_error.argtypes = [vp]
     _lib = L
     return L
 
@@ -250,6 +260,7 @@ def _c_options(options):
     o.provided = 0 if us.provided is None else us.provided
     o.memlimit_is_some = 0 if options.memlimit is None else 1
     o.memlimit = 0 if options.memlimit is None else options.memlimit
+    o.allow_incomplete = 1 if options.allow_incomplete else 0
     return o
 
 
@@ -571,6 +582,55 @@ class MultiContext:
 
     def xz_batch(self, datas):
         return self._batch(lib().milzma_multi_xz_decompress_batch, datas)
+
+
+class Streams:
+    """A batch of push-mode .lzma decoders: n x lzma_rs::decompress::Stream (feature `stream`, src/decode/stream.rs) on one GPU
+    (milzma_streams_*).  write({stream: bytes, ...}) is io::Write::write_all for each named stream -- the dict it returns maps a stream to
+    the text of the io::Error of a failed write (empty dict: every write succeeded); finish() is Stream::finish for every stream: a list
+    of Decoded."""
+
+    def __init__(self, ctx, n, options=None):
+        self.n = n
+        self._h = ctypes.c_void_p()
+        copts = None
+        if options is not None:
+            opts = options if isinstance(options, (list, tuple)) else [options] * n
+            assert len(opts) == n
+            copts = (_COptions * n)(*[_c_options(o) for o in opts])
+        if lib().milzma_streams_open(ctx._h, n, copts, ctypes.byref(self._h)) != OK:
+            raise InfraError("milzma_streams_open: " + ctx.last_error())
+
+    def write(self, pieces):
+        items = [(i, bytes(b)) for i, b in pieces.items()]
+        k = len(items)
+        idx = (ctypes.c_uint32 * k)(*[i for i, _ in items])
+        bufs = [_as_buffer(b) for _, b in items]
+        ptrs = (ctypes.c_void_p * k)(*[b[0] for b in bufs])
+        lens = (ctypes.c_size_t * k)(*[b[1] for b in bufs])
+        status = (ctypes.c_int32 * k)()
+        if lib().milzma_streams_write(self._h, k, idx, ptrs, lens, status) != OK:
+            raise InfraError("milzma_streams_write: " + lib().milzma_streams_last_error(self._h).decode())
+        return {items[j][0]: lib().milzma_streams_write_error(self._h, items[j][0]).decode() for j in range(k) if status[j] != OK}
+
+    def finish(self):
+        outs = (_COutput * self.n)()
+        rc = lib().milzma_streams_finish(self._h, outs)
+        decs = [Decoded(outs[i]) for i in range(self.n)]
+        if rc != OK:
+            raise InfraError("milzma_streams_finish: " + lib().milzma_streams_last_error(self._h).decode())
+        return decs
+
+    def close(self):
+        if self._h:
+            lib().milzma_streams_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default_ctx = None

@@ -449,7 +449,8 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     // The literal rows of every unit of the BATCH in one slab (indexed by unit, like the results: a unit keeps its rows across the
     // turns of a time-sliced launch and across a park / resume), every probability of THIS launch's units 0x400 before it starts.  Not
     // to be had (half of the free memory at most): the generic kernel's spill class takes the units, chunk by chunk.
-    uint32_t need = 4;   // (at least what an LZMA2 unit can switch to)
+    uint32_t need = std::max<uint32_t>(4, ctx->slab_min_lclp);   // (at least what an LZMA2 unit can switch to; a batch that takes new members
+                                                                 //  later -- MILZMA_KIND_START -- asks for room for theirs up front)
     for (uint32_t i : order) need = std::max<uint32_t>(need, uint32_t(ctx->pend_units[i].lc) + ctx->pend_units[i].lp);
     need = std::min<uint32_t>(need, 12);
     if (ctx->slab_live) {
@@ -605,6 +606,16 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
     ctx->err = "MILZMA_DECODE_FEED needs the asm kernel's launch classes (MILZMA_KERNEL / MILZMA_SPILL = generic set)";
     return MILZMA_INFRA_ERROR;
   }
+  // (a RESUME | FEED call may also START units -- MILZMA_KIND_START: continuous batching -- and so may be the first call of its batch)
+  bool starts = false;
+  if (resume && feed && units)
+    for (uint32_t i = 0; i < n && !starts; i++) starts = (units[i].kind & MILZMA_KIND_START) != 0;
+  if (resume && starts && prev && (!ctx->parked_valid || ctx->parked_n != n) && !ctx->pending) {
+    ctx->parked_valid = true;   // a batch of n places, nothing parked in it yet
+    ctx->parked_n = n;
+    ctx->park_rec.assign(n, milzma_ctx::ParkRec());
+    ctx->slab_live = false;
+  }
   if (resume && (!ctx->parked_valid || ctx->parked_n != n || !prev)) {
     ctx->err = "MILZMA_DECODE_RESUME: this context holds no parked units of a batch of that size";
     return MILZMA_INFRA_ERROR;
@@ -656,10 +667,16 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   // the same floor (the kernels divide by dict_size).
   ctx->pend_units.assign(units, units + n);
   for (milzma_unit& u : ctx->pend_units)
-    if ((u.kind & (feed ? 0x7Fu : 0xFFu)) == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
+    if ((u.kind & (feed ? 0x1Fu : 0xFFu)) == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
   // (fed input: MILZMA_KIND_LAST_VIEW is for the kernel; everything on the host side looks at the plain kind)
   ctx->feed_units.clear();
+  std::vector<uint8_t> marks;   // MILZMA_KIND_START / _HOLD of each unit (host side only: the device sees the kind and LAST_VIEW)
   if (feed) {
+    marks.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+      marks[i] = ctx->pend_units[i].kind & (MILZMA_KIND_START | MILZMA_KIND_HOLD);
+      ctx->pend_units[i].kind &= uint8_t(~(MILZMA_KIND_START | MILZMA_KIND_HOLD));
+    }
     ctx->feed_units = ctx->pend_units;
     for (milzma_unit& u : ctx->pend_units) u.kind &= uint8_t(~MILZMA_KIND_LAST_VIEW);
   }
@@ -669,8 +686,26 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   // Partition by launch class; inside a class longest input first, so that the hardware's
   // in-order block dispatch behaves like longest-processing-time-first scheduling.
   std::vector<uint32_t> order[kNumLitClasses];
+  std::vector<uint32_t> fresh[kNumLitClasses];   // RESUME | FEED: units that START in this call (launched like a first call's, beside the resumed ones)
   if (resume) {  // only what the previous call parked, each unit in the class the CONTEXT knows it was parked in
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t i = 0; i < n; i++) {
+      const uint8_t mark = feed ? marks[i] : 0;
+      if (mark & MILZMA_KIND_START) {   // a new member of the batch: its place must be free
+        const milzma_ctx::ParkRec* rec = i < ctx->park_rec.size() ? &ctx->park_rec[i] : nullptr;
+        LitClass c = classify(ctx, units[i]);
+        if (c == kFast && units[i].kind == MILZMA_KIND_LZMA2) c = kFastSpill;
+        const char* why = (rec && rec->parked && is_parked_result(prev[i])) ? "is parked: it cannot start again"
+                          : (c != kFast && c != kFastSpill)                 ? "is outside the asm kernel's launch classes"
+                                                                            : nullptr;
+        if (why) {
+          ctx->err = "MILZMA_KIND_START: unit " + std::to_string(i) + " " + why;
+          ctx->pending = false;
+          return MILZMA_INFRA_ERROR;
+        }
+        fresh[c].push_back(i);
+        continue;
+      }
+      if (mark & MILZMA_KIND_HOLD) continue;   // parked, and to stay so in this call (its result and its record are kept)
       if (is_parked_result(prev[i])) {
         // (a unit parked by a FEED call comes back with another view by design -- the caller vouches that it starts at the unit's first
         //  unused byte, there is nothing here to hold that against)
@@ -688,6 +723,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
         }
         order[rec->spill ? kFastSpill : kFast].push_back(i);
       }
+    }
   } else {
     // (fed LZMA2 units: with a slab from the start -- a property switch beyond lc + lp = 3 cannot send them back to a start that has gone)
     for (uint32_t i = 0; i < n; i++) {
@@ -736,6 +772,13 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
     base[c] = uint32_t(flat.size());
     flat.insert(flat.end(), order[c].begin(), order[c].end());
   }
+  const size_t n_resumed = flat.size();   // (what follows in `flat` starts fresh)
+  uint32_t fbase[kNumLitClasses];
+  for (int c = 0; c < kNumLitClasses; c++) {
+    std::stable_sort(fresh[c].begin(), fresh[c].end(), [&](uint32_t a, uint32_t b) { return units[a].in_len > units[b].in_len; });
+    fbase[c] = uint32_t(flat.size());
+    flat.insert(flat.end(), fresh[c].begin(), fresh[c].end());
+  }
 
   if (!dev_reserve(ctx, ctx->units, size_t(n) * sizeof(milzma_unit)) ||
       !dev_reserve(ctx, ctx->order, size_t(n) * 2 * sizeof(uint32_t)) ||
@@ -744,7 +787,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
     return fail();
   // (the order array is staged in page-locked memory behind the results so that its upload is asynchronous too)
   uint32_t* h_order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->pin_results.p) + size_t(n) * sizeof(milzma_result));
-  for (size_t k = 0; k < flat.size(); k++) h_order[k] = flat[k] | (resume ? 0x80000000u : 0u);  // (bit 31: resume from the parked state)
+  for (size_t k = 0; k < flat.size(); k++) h_order[k] = flat[k] | (resume && k < n_resumed ? 0x80000000u : 0u);  // (bit 31: resume from the parked state)
   if (!hip_ok(ctx, hipMemcpyAsync(ctx->units.p, units_up, size_t(n) * sizeof(milzma_unit), hipMemcpyHostToDevice, stream),
               "H2D units") ||
       (!flat.empty() &&
@@ -758,7 +801,9 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   }
 
   for (int c = 0; c < kNumLitClasses; c++)
-    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream, grow, resume, feed)) return fail();
+    if (!launch_class(ctx, LitClass(c), order[c], base[c], ctx->pend_in, ctx->pend_out, stream, grow, resume, feed) ||
+        !launch_class(ctx, LitClass(c), fresh[c], fbase[c], ctx->pend_in, ctx->pend_out, stream, grow, false, feed))
+      return fail();
 
   // (The results are fetched by the wait half, after the kernels: a copy queued behind a running kernel parks a DMA queue on
   //  that kernel's completion, and an unrelated upload of another context that lands on the same queue then waits for the whole

@@ -367,3 +367,44 @@ extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results)
   }
 }
 
+
+
+// ---- push-mode streams (host_stream.cpp) -----------------------------------------------------------------------------------------
+MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out);
+MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len, int32_t* status);
+MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* outs);
+MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S);
+MILZMA_HIDDEN const char* milzma_streams_write_error_impl(const milzma_streams* S, uint32_t stream);
+MILZMA_HIDDEN const char* milzma_streams_last_error_impl(const milzma_streams* S);
+
+extern "C" int milzma_streams_open(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out) {
+  begin_call(ctx);
+  try {
+    return milzma_streams_open_impl(ctx, n, options, out);
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = std::string("host exception: ") + e.what();
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_streams_write(milzma_streams* s, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len, int32_t* status) {
+  try {
+    return milzma_streams_write_impl(s, k, idx, data, len, status);
+  } catch (const std::exception&) {  // (std::bad_alloc while buffering: nothing was launched with half-built descriptors -- the round builds them first)
+    if (status)
+      for (uint32_t j = 0; j < k; j++) status[j] = MILZMA_INFRA_ERROR;
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" int milzma_streams_finish(milzma_streams* s, milzma_output* outs) {
+  try {
+    return milzma_streams_finish_impl(s, outs);
+  } catch (const std::exception&) {
+    return MILZMA_INFRA_ERROR;
+  }
+}
+
+extern "C" void milzma_streams_close(milzma_streams* s) { milzma_streams_close_impl(s); }
+extern "C" const char* milzma_streams_write_error(const milzma_streams* s, uint32_t stream) { return milzma_streams_write_error_impl(s, stream); }
+extern "C" const char* milzma_streams_last_error(const milzma_streams* s) { return milzma_streams_last_error_impl(s); }

@@ -134,6 +134,7 @@ struct milzma_ctx {
   // neither re-derive the stride from it nor wipe the other units' rows.
   bool slab_live = false;
   uint32_t slab_lclp = 0;
+  uint32_t slab_min_lclp = 0;   // rows per unit (as lc + lp) the slab is made for at least: a batch whose members start later (host_stream.cpp)
   // Streamed launches (the whole-file calls' progressive download): a caller that sets stream_span / stream_spans before the async
   // half asks for the batch's ONE fast launch to run time-sliced with span counters (kernels.h); stream_active says it happened.
   // progress: kMaxSpans counters in mapped host memory, written by the device, polled by SpanPump.
@@ -385,6 +386,7 @@ int out_fail(milzma_output* o, int kind, const char* fmt, ...);
 int out_io_eof(milzma_output* o);
 bool out_set_data(milzma_output* o, const uint8_t* p, size_t n);
 int infra(milzma_ctx* ctx, milzma_output* o);
+int finish_stream(const milzma_result& r, uint32_t kind, const uint8_t* slice, size_t slice_len, size_t header_len, milzma_output* out);
 bool upload_host_ptrs(milzma_ctx* ctx, const std::vector<uint64_t>& ptrs, hipStream_t ws);
 void stream_minimum(size_t* units, size_t* bytes, bool* ragged_ok = nullptr);
 bool pinned_results_wanted();

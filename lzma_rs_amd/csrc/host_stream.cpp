@@ -1,0 +1,384 @@
+// host_stream.cpp -- push-mode .lzma decoding for a BATCH of streams: lzma_rs::decompress::Stream (feature `stream`,
+// src/decode/stream.rs) on top of fed input (MILZMA_DECODE_FEED).  See host_internal.h for the map of the host side.
+//
+// One `milzma_streams` is n independent `Stream<Vec<u8>>` objects that share a context of their own (a batch of n places in its
+// parking lot): a write call appends bytes to some of them and runs ONE resuming launch in which every stream that got bytes takes
+// another turn -- streams whose header has just become complete start in that launch (MILZMA_KIND_START), streams that got nothing
+// stay parked (MILZMA_KIND_HOLD).  What the reference does per stream and call, and where it is restated here:
+//   * State::Header (stream.rs:228-303): bytes are kept until the .lzma header and the range coder's five start bytes are there; a
+//     property byte >= 225 fails the write that delivers it;
+//   * State::Data (stream.rs:305-316, lzma.rs:435-524 in ProcessingMode::Partial): symbols are decoded while at least
+//     MAX_REQUIRED_INPUT = 20 bytes are at hand -- the kernel's FEED margin is that very number --; the reference also decodes a symbol
+//     that a TRIAL run shows to be complete within fewer bytes, the kernel leaves those for the next call.  Both stop in front of the
+//     same truncated symbol, so the difference shows only in WHEN an error inside the last 19 bytes of a call's data is reported (here:
+//     with the next call, or by finish) and in nothing a finished stream hands over;
+//   * finish (stream.rs:119-150): the last view runs with MILZMA_KIND_LAST_VIEW; with allow_incomplete what stops in front of an
+//     incomplete symbol is a success with everything decoded so far.
+#include "host_internal.h"
+
+using namespace milzma;
+using namespace milzma::host;
+
+namespace {
+
+struct One {
+  enum St : uint8_t { HEADER, DATA, DONE, FAILED } st = HEADER;
+  milzma_options opt;
+  std::vector<uint8_t> pending;   // HEADER: the header bytes so far; DATA: payload that has arrived and is not consumed yet
+  size_t hdr_len = 0;
+  uint64_t consumed = 0;           // payload bytes the decoder has taken
+  bool started = false;            // its unit has been launched (it owns an output slice)
+  bool marker_done = false;        // ended by its end marker / by the end of input: nothing more can be written to it
+  std::string write_err;           // text of the io::Error of the write that failed
+};
+
+// the io::Error a failed Stream::write returns for a decode error: io::Error::new(Other, format!("{:?}", error)) (stream.rs:343-347);
+// Debug of error::Error::LzmaError(String) is LzmaError("...")
+std::string debug_lzma_error(const milzma_result& r) {
+  char msg[400];
+  milzma_result_message(&r, MILZMA_KIND_RAW_LZMA, msg, sizeof msg);
+  const char* m = strchr(msg, ':');
+  return std::string("LzmaError(\"") + (m ? m + 2 : msg) + "\")";
+}
+
+}  // namespace
+
+struct milzma_streams {
+  milzma_ctx* ctx = nullptr;   // its own: the parking lot of a context belongs to one batch
+  uint32_t n = 0;
+  std::vector<One> s;
+  std::vector<milzma_unit> units;
+  std::vector<milzma_result> res;
+  DevBuf out;                  // the streams' output slices
+  size_t out_used = 0;
+  bool finished = false;
+};
+
+MILZMA_HOST_NS_BEGIN
+
+static bool parked(const milzma_result& r) { return is_parked_result(r); }
+
+// New slices for the streams in `want` (stream -> capacity), everything that has produced output moved along: one fresh buffer, packed.
+static bool regrow(milzma_streams* S, const std::vector<std::pair<uint32_t, uint64_t>>& want) {
+  milzma_ctx* ctx = S->ctx;
+  std::vector<uint64_t> cap(S->n, 0);
+  for (uint32_t i = 0; i < S->n; i++)
+    if (S->s[i].started) cap[i] = S->units[i].out_cap;
+  for (const auto& w : want) cap[w.first] = std::max<uint64_t>(cap[w.first], std::min<uint64_t>(round_up(size_t(w.second), 256), MILZMA_MAX_UNIT_BYTES));
+  size_t total = 0;
+  std::vector<uint64_t> off(S->n, 0), so, dof, ln;
+  for (uint32_t i = 0; i < S->n; i++) {
+    off[i] = total;
+    total += round_up(size_t(cap[i]), 256);
+  }
+  DevBuf fresh;
+  if (!dev_reserve(ctx, fresh, total + 512)) return false;
+  for (uint32_t i = 0; i < S->n; i++) {
+    const uint64_t have = S->s[i].started ? std::min<uint64_t>(S->res[i].out_len, S->units[i].out_cap) : 0;
+    if (have) {
+      so.push_back(S->units[i].out_off);
+      dof.push_back(off[i]);
+      ln.push_back(have);
+    }
+  }
+  if (!so.empty() && move_units_impl(ctx, uint32_t(so.size()), S->out.p, so.data(), fresh.p, dof.data(), ln.data(), work_stream(ctx)) != MILZMA_OK) {
+    dev_release(fresh);
+    return false;
+  }
+  dev_release(S->out);
+  S->out = fresh;
+  S->out_used = total;
+  for (uint32_t i = 0; i < S->n; i++) {
+    S->units[i].out_off = off[i];
+    S->units[i].out_cap = cap[i];
+  }
+  return true;
+}
+
+// One turn for the streams in `active` (state DATA): their pending bytes are their views; `last`: the views end where the streams end.
+// Streams that run out of room get larger slices and go on until they need input (or end).  Updates pending / consumed / res.
+static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool last) {
+  milzma_ctx* ctx = S->ctx;
+  // slices for the streams that start now
+  {
+    std::vector<std::pair<uint32_t, uint64_t>> want;
+    for (uint32_t i : active)
+      if (!S->s[i].started) {
+        const milzma_unit& u = S->units[i];
+        const uint64_t plausible = std::max<uint64_t>(uint64_t(1) << 20, uint64_t(S->s[i].pending.size()) * 1024);
+        uint64_t cap = std::max<uint64_t>(1 << 16, uint64_t(S->s[i].pending.size()) * 8);
+        if (u.unpacked_size != MILZMA_SIZE_UNKNOWN) cap = std::min<uint64_t>(u.unpacked_size, plausible) + 512;
+        if (u.memlimit < u.dict_size) cap = std::min<uint64_t>(cap, u.memlimit + 512);   // (ends at memlimit bytes: lzbuffer.rs:206-217)
+        want.emplace_back(i, cap);
+      }
+    if (!want.empty()) {
+      for (const auto& w : want) {
+        S->s[w.first].started = true;
+        S->units[w.first].out_cap = 0;
+        memset(&S->res[w.first], 0, sizeof(milzma_result));
+      }
+      if (!regrow(S, want)) return false;
+      for (const auto& w : want) S->units[w.first].kind = MILZMA_KIND_RAW_LZMA | MILZMA_KIND_START;   // (marks this round only)
+    }
+  }
+  for (int round = 0; !active.empty(); round++) {
+    if (round > 64) {
+      ctx->err = "a stream keeps asking for room";
+      return false;
+    }
+    std::vector<uint8_t> is_active(S->n, 0);
+    size_t in_total = 0;
+    for (uint32_t i : active) {
+      is_active[i] = 1;
+      S->units[i].in_off = in_total;
+      S->units[i].in_len = S->s[i].pending.size();
+      in_total += round_up(S->s[i].pending.size(), 64) + 64;
+    }
+    if (!pin_reserve(ctx, ctx->pin_in, in_total + 512) || !dev_reserve(ctx, ctx->in, in_total + 512)) return false;
+    for (uint32_t i : active)
+      if (!S->s[i].pending.empty()) memcpy(static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off, S->s[i].pending.data(), S->s[i].pending.size());
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
+        !hip_ok(ctx, hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_total, hipMemcpyHostToDevice, work_stream(ctx)), "H2D views"))
+      return false;
+    for (uint32_t i = 0; i < S->n; i++) {
+      uint8_t k = S->units[i].kind & (MILZMA_KIND_START | 0x1Fu);
+      if (!is_active[i]) {
+        k &= uint8_t(~MILZMA_KIND_START);
+        if (parked(S->res[i])) k |= MILZMA_KIND_HOLD;
+      } else if (last) {
+        k |= MILZMA_KIND_LAST_VIEW;
+      }
+      S->units[i].kind = k;
+    }
+    const int rc = milzma_decode_units_impl(ctx, S->units.data(), S->n, ctx->in.p, S->out.p, S->res.data(), work_stream(ctx),
+                                            MILZMA_DECODE_RESUME | MILZMA_DECODE_FEED);
+    for (uint32_t i = 0; i < S->n; i++) S->units[i].kind &= 0x1Fu;
+    if (rc != MILZMA_OK) return false;
+    std::vector<uint32_t> again;
+    std::vector<std::pair<uint32_t, uint64_t>> want;
+    for (uint32_t i : active) {
+      One& o = S->s[i];
+      const milzma_result& r = S->res[i];
+      const uint64_t took = std::min<uint64_t>(r.in_consumed, o.pending.size());
+      o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(took));
+      o.consumed += took;
+      if (parked(r) && r.status == MILZMA_ST_OUT_FULL) {   // more room: what its progress predicts for the bytes at hand, at least 2.5 x
+        const long double rate = (long double)(r.out_len + 1) / (long double)std::max<uint64_t>(1, o.consumed);
+        uint64_t cap = uint64_t(rate * (long double)(o.consumed + o.pending.size()) * 1.25L) + 65536;
+        cap = std::max<uint64_t>(cap, S->units[i].out_cap * 5 / 2 + 4096);
+        if (S->units[i].unpacked_size != MILZMA_SIZE_UNKNOWN && S->units[i].unpacked_size + 512 > r.out_len + 274)
+          cap = std::min<uint64_t>(cap, S->units[i].unpacked_size + 512);
+        want.emplace_back(i, cap);
+        again.push_back(i);
+      }
+    }
+    if (!want.empty() && !regrow(S, want)) return false;
+    active.swap(again);
+  }
+  return true;
+}
+
+MILZMA_HOST_NS_END
+
+MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out) {
+  if (!ctx || !out) return MILZMA_INFRA_ERROR;
+  *out = nullptr;
+  if (!(ctx->use_fast && ctx->fast_spill)) {
+    ctx->err = "push-mode streams need the asm kernel's launch classes (MILZMA_KERNEL / MILZMA_SPILL = generic set)";
+    return MILZMA_INFRA_ERROR;
+  }
+  milzma_ctx* own = nullptr;
+  if (milzma_create(ctx->device, &own) != MILZMA_OK) {
+    ctx->err = std::string("push-mode streams: ") + milzma_last_error(nullptr);
+    return MILZMA_INFRA_ERROR;
+  }
+  auto* S = new milzma_streams();
+  S->ctx = own;
+  S->n = n;
+  S->s.resize(n);
+  S->units.resize(n);
+  S->res.resize(n);
+  milzma_options dflt;
+  milzma_default_options(&dflt);
+  for (uint32_t i = 0; i < n; i++) {
+    S->s[i].opt = options ? options[i] : dflt;
+    memset(&S->units[i], 0, sizeof(milzma_unit));
+    memset(&S->res[i], 0, sizeof(milzma_result));
+  }
+  // literal rows for streams that join later: as many per stream as a quarter of the free memory allows (lc + lp up to 8 by default)
+  size_t free_b = 0, total_b = 0;
+  uint32_t lclp = 8;
+  if (hipSetDevice(own->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    while (lclp > 4 && (size_t(1536) << lclp) * std::max<uint32_t>(n, 1) > free_b / 4) lclp--;
+  own->slab_min_lclp = lclp;
+  *out = S;
+  return MILZMA_OK;
+}
+
+MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len,
+                                           int32_t* status) {
+  if (!S) return MILZMA_INFRA_ERROR;
+  milzma_ctx* ctx = S->ctx;
+  ctx->err.clear();
+  if (S->finished) {
+    ctx->err = "the streams have been finished";
+    return MILZMA_INFRA_ERROR;
+  }
+  if (k && (!idx || !data || !len)) {
+    ctx->err = "null arguments";
+    return MILZMA_INFRA_ERROR;
+  }
+  std::vector<uint8_t> seen(S->n, 0);
+  for (uint32_t j = 0; j < k; j++) {
+    if (idx[j] >= S->n || seen[idx[j]] || (len[j] && !data[j])) {
+      ctx->err = "stream " + std::to_string(idx[j]) + ": not a stream of this batch, named twice in one call, or null data";
+      return MILZMA_INFRA_ERROR;
+    }
+    seen[idx[j]] = 1;
+  }
+  std::vector<uint32_t> active;
+  std::vector<int32_t> st(k, MILZMA_OK);
+  for (uint32_t j = 0; j < k; j++) {
+    One& o = S->s[idx[j]];
+    o.write_err.clear();
+    if (len[j] == 0) continue;   // (write_all of nothing calls nobody: std::io::Write::write_all)
+    const uint8_t* p = static_cast<const uint8_t*>(data[j]);
+    switch (o.st) {
+      case One::FAILED:          // Stream.state is None: write() takes everything and does nothing (stream.rs:227-229, :324-325)
+        break;
+      case One::DONE:
+        // the declared size is reached: write() takes nothing, write_all reports ErrorKind::WriteZero (lzma.rs:441-445; tests/lzma.rs:71-87).
+        // (Behind an end marker the reference would decode on from the marker's state; that is not followed: same answer.)
+        o.write_err = "failed to write whole buffer";
+        st[j] = MILZMA_IO_ERROR;
+        break;
+      case One::HEADER: {
+        o.pending.insert(o.pending.end(), p, p + len[j]);
+        milzma_unit u;
+        size_t hl = 0;
+        milzma_output ho;
+        const int hr = milzma_lzma_read_header(o.pending.data(), o.pending.size(), &o.opt, &u, &hl, &ho);
+        if (hr == MILZMA_HEADER_TOO_SHORT) break;   // need more data, try again later (stream.rs:185)
+        if (hr != MILZMA_OK) {                      // fatal: LzmaError(s) => io::Error::new(Other, s) (stream.rs:291-299)
+          const char* m = strchr(ho.msg, ':');
+          o.write_err = m ? m + 2 : ho.msg;
+          o.st = One::FAILED;
+          st[j] = MILZMA_IO_ERROR;
+          break;
+        }
+        if (o.pending.size() - hl < 5) break;       // RangeDecoder::new needs five bytes: Header again (stream.rs:176-180)
+        o.hdr_len = hl;
+        o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(hl));
+        u.out_off = u.out_cap = 0;
+        S->units[idx[j]] = u;
+        o.st = One::DATA;
+        active.push_back(idx[j]);
+        break;
+      }
+      case One::DATA:
+        o.pending.insert(o.pending.end(), p, p + len[j]);
+        active.push_back(idx[j]);
+        break;
+    }
+  }
+  if (!active.empty() && !feed_round(S, active, false)) {
+    if (status)
+      for (uint32_t j = 0; j < k; j++) status[j] = MILZMA_INFRA_ERROR;
+    return MILZMA_INFRA_ERROR;
+  }
+  for (uint32_t j = 0; j < k; j++) {
+    const uint32_t i = idx[j];
+    One& o = S->s[i];
+    if (o.st != One::DATA || !seen[i] || len[j] == 0) continue;
+    const milzma_result& r = S->res[i];
+    if (parked(r)) continue;
+    if (r.status == MILZMA_ST_OK || r.status == MILZMA_ST_SIZE_MISMATCH) {
+      // the stream has ended (its size is reached, or its end marker has been read with nothing behind it): Partial mode leaves its loop;
+      // "Expected unpacked size ..." is a check of finish() (lzma.rs:513-521, Finish mode only)
+      o.st = One::DONE;
+      if (!o.pending.empty()) {
+        o.write_err = "failed to write whole buffer";
+        st[j] = MILZMA_IO_ERROR;
+      }
+    } else {
+      o.write_err = debug_lzma_error(r);
+      o.st = One::FAILED;
+      st[j] = MILZMA_IO_ERROR;
+    }
+  }
+  if (status)
+    for (uint32_t j = 0; j < k; j++) status[j] = st[j];
+  return MILZMA_OK;
+}
+
+MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* outs) {
+  if (!S || !outs) return MILZMA_INFRA_ERROR;
+  milzma_ctx* ctx = S->ctx;
+  ctx->err.clear();
+  if (S->finished) {
+    ctx->err = "the streams have been finished";
+    return MILZMA_INFRA_ERROR;
+  }
+  S->finished = true;
+  for (uint32_t i = 0; i < S->n; i++) out_reset(&outs[i]);
+  std::vector<uint32_t> active;
+  for (uint32_t i = 0; i < S->n; i++)
+    if (S->s[i].st == One::DATA) active.push_back(i);
+  // (with allow_incomplete the reference skips the last pass altogether -- what it has is everything a trial run found complete; here
+  //  that is what the last view decodes before it stops in front of the incomplete symbol)
+  if (!active.empty() && !feed_round(S, active, true)) {
+    for (uint32_t i = 0; i < S->n; i++) infra(ctx, &outs[i]);
+    return MILZMA_INFRA_ERROR;
+  }
+  int worst = MILZMA_OK;
+  std::vector<uint8_t> host;
+  for (uint32_t i = 0; i < S->n; i++) {
+    One& o = S->s[i];
+    milzma_output* out = &outs[i];
+    if (o.st == One::HEADER) {   // stream.rs:122-128
+      if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");
+      out->in_consumed = 0;
+      continue;
+    }
+    if (o.st == One::FAILED) {   // stream.rs:144-148
+      out_fail(out, MILZMA_LZMA_ERROR, "can't finish stream because of previous write error");
+      continue;
+    }
+    milzma_result r = S->res[i];
+    const bool incomplete_ok =
+        o.opt.allow_incomplete && (r.status == MILZMA_ST_INPUT_EOF || r.status == MILZMA_ST_MATCH_DIST_DICT || r.status == MILZMA_ST_MATCH_DIST_OUT ||
+                                   r.status == MILZMA_ST_SIZE_MISMATCH);
+    if (incomplete_ok) {   // stops in front of a symbol a trial run would not get through (lzma.rs:401-417), no end-of-stream checks: Ok
+      r.status = MILZMA_ST_OK;
+      r.out_flushed = r.out_len;
+    }
+    const size_t visible = size_t(std::min<uint64_t>(r.out_flushed, S->units[i].out_cap));
+    host.resize(visible);
+    if (visible && !hip_ok(ctx, hipMemcpy(host.data(), static_cast<const uint8_t*>(S->out.p) + S->units[i].out_off, visible, hipMemcpyDeviceToHost),
+                           "D2H output")) {
+      infra(ctx, out);
+      worst = MILZMA_INFRA_ERROR;
+      continue;
+    }
+    r.in_consumed = o.consumed;   // (what finish_stream adds the header to: the whole stream's reader position)
+    finish_stream(r, MILZMA_KIND_RAW_LZMA, host.data(), visible, o.hdr_len, out);
+  }
+  return worst;
+}
+
+MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S) {
+  if (!S) return;
+  if (S->ctx) {
+    (void)hipSetDevice(S->ctx->device);
+    dev_release(S->out);
+    milzma_destroy(S->ctx);
+  }
+  delete S;
+}
+
+MILZMA_HIDDEN const char* milzma_streams_write_error_impl(const milzma_streams* S, uint32_t stream) {
+  if (!S || stream >= S->n) return "";
+  return S->s[stream].write_err.c_str();
+}
+
+MILZMA_HIDDEN const char* milzma_streams_last_error_impl(const milzma_streams* S) { return S && S->ctx ? S->ctx->err.c_str() : "no streams"; }

@@ -442,6 +442,98 @@ bool raw_feed_loop(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, const st
   return ok;
 }
 
+// 3e. the push-mode API (milzma_streams_*: lzma_rs::decompress::Stream for a batch): good .lzma files written in four pieces each, on
+// schedules of their own -- some streams join calls later (MILZMA_KIND_START inside a resuming call), all of them sit calls out
+// (MILZMA_KIND_HOLD) --, one with a bad header, one never completed; finish against the one-shot oracle.
+bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool) {
+  std::vector<const Case*> files;
+  std::vector<orc_result> want;
+  for (const Case& c : lzma_pool) {
+    if (files.size() >= 14) break;
+    orc_result w;
+    memset(&w, 0, sizeof w);
+    orc_lzma_decompress(ptr_of(c.data), c.data.size(), nullptr, &w);
+    if (w.kind != ORC_OK || c.data.size() < 120 || w.in_consumed != c.data.size()) {
+      orc_free(w.out);
+      continue;
+    }
+    files.push_back(&c);
+    want.push_back(w);
+  }
+  bool ok = true;
+  const uint32_t n = uint32_t(files.size()) + 2;   // + a stream with a bad header, + one that gets only half a header
+  milzma_streams* S = nullptr;
+  if (files.size() < 3) {
+    for (orc_result& w : want) orc_free(w.out);
+    return true;
+  }
+  if (milzma_streams_open(ctx, n, nullptr, &S) != MILZMA_OK) {
+    printf("INFRA streams_open: %s\n", milzma_last_error(ctx));
+    ok = false;
+  }
+  const uint8_t bad_header[20] = {255, 1, 2, 3};
+  for (int call = 0; ok && call < 11; call++) {
+    std::vector<uint32_t> idx;
+    std::vector<const void*> data;
+    std::vector<size_t> len;
+    for (uint32_t i = 0; i < uint32_t(files.size()); i++) {
+      const int start = int(i % 4), piece = (call - start) / 1;
+      if (call < start || (call - start) % 2 || piece / 2 >= 4) continue;   // every second call from its start on: four pieces
+      const size_t total = files[i]->data.size(), q = piece / 2;
+      const size_t a = total * q / 4, b = q == 3 ? total : total * (q + 1) / 4;
+      idx.push_back(i);
+      data.push_back(ptr_of(files[i]->data) + a);
+      len.push_back(b - a);
+    }
+    if (call == 1) {
+      idx.push_back(n - 2);
+      data.push_back(bad_header);
+      len.push_back(sizeof bad_header);
+      idx.push_back(n - 1);
+      data.push_back(ptr_of(files[0]->data));
+      len.push_back(7);
+    }
+    std::vector<int32_t> st(idx.size(), -1);
+    if (milzma_streams_write(S, uint32_t(idx.size()), idx.data(), data.data(), len.data(), st.data()) != MILZMA_OK) {
+      printf("INFRA streams_write, call %d: %s\n", call, milzma_streams_last_error(S));
+      ok = false;
+      break;
+    }
+    for (size_t j = 0; j < idx.size(); j++) {
+      const bool should_fail = idx[j] == n - 2;
+      if ((st[j] != MILZMA_OK) != should_fail || (should_fail && !strstr(milzma_streams_write_error(S, idx[j]), "must be < 225"))) {
+        printf("MISMATCH streams_write: stream %u status %d (%s)\n", idx[j], st[j], milzma_streams_write_error(S, idx[j]));
+        ok = false;
+      }
+    }
+  }
+  if (ok) {
+    std::vector<milzma_output> outs(n);
+    if (milzma_streams_finish(S, outs.data()) == MILZMA_INFRA_ERROR) {
+      printf("INFRA streams_finish: %s\n", milzma_streams_last_error(S));
+      ok = false;
+    }
+    for (uint32_t i = 0; i < n && ok; i++) {
+      g_cases++;
+      g_compared++;
+      const milzma_output& o = outs[i];
+      if (i < files.size()) {
+        if (o.kind != MILZMA_OK || o.len != want[i].out_len || (o.len && memcmp(o.data, want[i].out, o.len) != 0) || o.in_consumed != files[i]->data.size()) {
+          printf("MISMATCH stream %u (%s): kind %d '%s' len %zu (want %zu)\n", i, files[i]->name.c_str(), o.kind, o.msg, o.len, want[i].out_len);
+          ok = false;
+        }
+      } else if (o.kind != MILZMA_LZMA_ERROR || !strstr(o.msg, i == n - 2 ? "previous write error" : "failed to read header")) {
+        printf("MISMATCH stream %u: kind %d '%s'\n", i, o.kind, o.msg);
+        ok = false;
+      }
+    }
+    for (milzma_output& o : outs) milzma_free(o.data);
+  }
+  milzma_streams_close(S);
+  for (orc_result& w : want) orc_free(w.out);
+  return ok;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -810,6 +902,7 @@ int main(int argc, char** argv) {
     for (auto& w : want) orc_free(w.out);
     if (ok) ok = raw_grow_loop(ctx, pool[LZMA], pool[LZMA2]);
     if (ok) ok = raw_feed_loop(ctx, pool[LZMA], pool[LZMA2]);
+    if (ok) ok = streams_api(ctx, pool[LZMA]);
     // milzma_xz_plan: the Index of a good file -> one unit per block; decoded, every block's bytes where the plan put them
     for (const Case& c : pool[XZ]) {
       if (!ok) break;
