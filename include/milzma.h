@@ -100,7 +100,7 @@ enum {
   MILZMA_ST_NEED_GENERIC = 35, /* props outside the fast kernel's specialisation: rerun in the generic one */
   MILZMA_ST_NEED_RERUN = 36,  /* internal to the whole-file calls' streamed launches (their input goes up in two parts): a unit read
                                  beyond the part that was in place: its output is void, it is decoded again                      */
-  MILZMA_ST_NEED_INPUT = 37   /* MILZMA_DECODE_FEED: the unit stopped within 32 bytes of the end of its input VIEW (err_a ==
+  MILZMA_ST_NEED_INPUT = 37   /* MILZMA_DECODE_FEED: the unit stopped within 20 bytes of the end of its input VIEW (err_a ==
                                  MILZMA_PARKED, always); in_consumed = bytes of the view it has used.  Resume it with a view that
                                  starts at that byte                                                                            */
 };
@@ -178,7 +178,7 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *   MILZMA_DECODE_FEED    (implies GROW) fed input -- the reference's streaming front end (`impl Write for Stream`, src/decode/stream.rs:223-283:
  *                         the caller hands the compressed bytes over piece by piece; lzma.rs:435-524 `process_mode(Partial)` decodes
  *                         a symbol only while MAX_REQUIRED_INPUT = 20 bytes are at hand or a trial run shows that fewer suffice).  Every unit's (in_off, in_len) is a VIEW: the bytes of its
- *                         stream that are on the device so far.  A unit that comes within 32 bytes of its view's end stops at a
+ *                         stream that are on the device so far.  A unit that comes within 20 bytes of its view's end stops at a
  *                         symbol boundary (an LZMA2 unit also: in front of a packet header or a stored chunk that is not inside the
  *                         view) and is parked with (MILZMA_ST_NEED_INPUT, err_a = MILZMA_PARKED, in_consumed = bytes of THIS view it
  *                         has used, out_len = bytes produced so far).  EVERY unit a FEED call parks -- for input or, as under GROW,

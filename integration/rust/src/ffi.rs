@@ -33,7 +33,7 @@ pub const MILZMA_USE_PROVIDED: i32 = 2;
 
 pub const MILZMA_ST_OK: u32 = 0;
 pub const MILZMA_ST_OUT_FULL: u32 = 32;
-/// `MILZMA_DECODE_FEED`: the unit stopped within 32 bytes of the end of its input view (`err_a == MILZMA_PARKED`)
+/// `MILZMA_DECODE_FEED`: the unit stopped within 20 bytes of the end of its input view (`err_a == MILZMA_PARKED`)
 pub const MILZMA_ST_NEED_INPUT: u32 = 37;
 /// `milzma_result.err_a` of a unit that stopped for room and can be resumed (MILZMA_DECODE_RESUME)
 pub const MILZMA_PARKED: u64 = 1;

@@ -123,7 +123,7 @@ impl Context {
     /// call's results; only the parked units run.  Nothing is decoded twice.
     ///
     /// With `ffi::MILZMA_DECODE_FEED` -- the device-resident counterpart of `impl Write for Stream` (src/decode/stream.rs:223-283) -- a
-    /// unit's `in_off / in_len` name a VIEW of its stream: the bytes that have arrived so far.  A unit that comes within 32 bytes of the
+    /// unit's `in_off / in_len` name a VIEW of its stream: the bytes that have arrived so far.  A unit that comes within 20 bytes of the
     /// view's end comes back as `status == MILZMA_ST_NEED_INPUT`, `err_a == MILZMA_PARKED`, `in_consumed` = bytes of this view it has
     /// used; resume it (`RESUME | FEED`) with a view that starts at that byte -- the unused tail in front of what has arrived since --
     /// and set `ffi::MILZMA_KIND_LAST_VIEW` in `kind` once its view ends where its stream ends (`Stream::finish`).

@@ -36,7 +36,7 @@ ST_OK = 0
 ST_OUT_FULL = 32
 PARKED = 1                      # Result.err_a of a unit that stopped for room and can be resumed (MILZMA_PARKED)
 DECODE_GROW, DECODE_RESUME, DECODE_FEED = 1, 2, 4   # flags of decode_units_ex (MILZMA_DECODE_*)
-ST_NEED_INPUT = 37              # ... DECODE_FEED: parked within 32 bytes of the end of its input view (err_a == PARKED)
+ST_NEED_INPUT = 37              # ... DECODE_FEED: parked within 20 bytes of the end of its input view (err_a == PARKED)
 KIND_LAST_VIEW = 0x80           # or-ed into Unit.kind in a DECODE_FEED call: the view ends where the stream ends
 
 
@@ -343,7 +343,7 @@ class Context:
     def decode_units_ex(self, units, d_in, d_out, flags, results=None, stream=0):
         """milzma_decode_units_ex: DECODE_GROW parks units that run out of room (Result.status == ST_OUT_FULL, err_a == PARKED);
         DECODE_RESUME (with the previous call's `results`) continues them in their new, larger slices.
-        DECODE_FEED: every unit's (in_off, in_len) is a view of a stream that goes on; units that come within 32 bytes of its end park
+        DECODE_FEED: every unit's (in_off, in_len) is a view of a stream that goes on; units that come within 20 bytes of its end park
         (ST_NEED_INPUT, err_a == PARKED) and are resumed with a view that starts at their first unused byte (include/milzma.h).
         Returns (results, kernel_ms, launches); `results` is updated in place when given."""
         n = len(units)

@@ -8,6 +8,7 @@
 //   host_api.cpp    the exported entry points' wrappers (no C++ exception crosses the ABI), calls cut into groups over lanes, the
 //                   asynchronous halves
 //   host_multi.cpp  the GPUs of one node behind one handle: partition planner, per-device workers, the one-ingest-point entry
+//   host_stream.cpp push-mode .lzma decoding for a batch of streams (the crate's Stream) over fed input
 //
 // Round 5 split what was one 3 900-line translation unit along the seams the fault-injection harness exercises;
 // behaviour is unchanged.  Everything internal lives in namespace milzma::host with hidden visibility: libmilzma.so exports the

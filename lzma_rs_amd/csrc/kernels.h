@@ -53,7 +53,7 @@ uint32_t stream_lead_bytes(uint32_t in_len);
 // span by span; progress: n_spans counters in such memory, counter s = units whose span s has arrived (see SliceQueue)
 // grow: growable output (milzma_decode_units_ex) -- a unit that runs out of room is parked in d_ctxmem with status OUT_FULL /
 // err_a = MILZMA_PARKED; d_order entries with bit 31 set resume such a unit (parked by an earlier launch with the same d_ctxmem)
-// feed: fed input (MILZMA_DECODE_FEED) -- a unit that comes within 32 bytes of the end of its input view is parked the same way with
+// feed: fed input (MILZMA_DECODE_FEED) -- a unit that comes within 20 bytes of the end of its input view is parked the same way with
 // status NEED_INPUT; resumed, its reader moves to the start of the view its descriptor then names
 
 // every probability (u16) of the literal-row slabs of the units d_order[0 .. n) = 0x400: d_slab + unit * slab_bytes, slab_bytes each.  Only

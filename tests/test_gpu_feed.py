@@ -1,7 +1,7 @@
 """GPU parity of fed input (MILZMA_DECODE_FEED): the input-side counterpart of growable output.
 
 The reference's streaming front end (src/decode/stream.rs:223-283 `impl Write for Stream`, lzma.rs:435-524 `process_mode(Partial)`) takes the compressed
-bytes piece by piece.  Here every unit's descriptor names a VIEW of its stream; a unit that comes within 32 bytes of the view's end parks
+bytes piece by piece.  Here every unit's descriptor names a VIEW of its stream; a unit that comes within 20 bytes of the view's end parks
 (MILZMA_ST_NEED_INPUT) and resumes on a view that starts at its first unused byte.  The tests cut streams of every kind at random places,
 move the unused tails around in the input buffer (any alignment), mix input parks with room parks, and compare the end result -- verdict,
 message, bytes, reader position -- with the oracle's one-shot decode of the whole stream.
@@ -90,7 +90,7 @@ def _feed_until_done(ctx, comps, kinds, heads, out_caps, rng, piece, relocate=Tr
             assert res[i].in_consumed <= units[i].in_len, (i, res[i].in_consumed, units[i].in_len)
             if res[i].status == M.ST_NEED_INPUT:
                 counts["input_parks"] += 1
-                # within 32 bytes of the view's end (an LZMA2 unit: or in front of a packet that is not inside it), and never on the last view
+                # within 20 bytes of the view's end (an LZMA2 unit: or in front of a packet that is not inside it), and never on the last view
                 assert avail[i] < len(payload[i]) or units[i].in_len - res[i].in_consumed <= 0xFFFF + 32, i
                 if kinds[i] == M.KIND_RAW_LZMA:
                     assert units[i].in_len - res[i].in_consumed < 32, (i, units[i].in_len, res[i].in_consumed)
