@@ -602,12 +602,12 @@ class Streams:
             raise InfraError("milzma_streams_open: " + ctx.last_error())
 
     def write(self, pieces):
-        items = [(i, bytes(b)) for i, b in pieces.items()]
+        items = [(i, b if isinstance(b, bytes) else bytes(b)) for i, b in pieces.items()]
         k = len(items)
         idx = (ctypes.c_uint32 * k)(*[i for i, _ in items])
-        bufs = [_as_buffer(b) for _, b in items]
-        ptrs = (ctypes.c_void_p * k)(*[b[0] for b in bufs])
-        lens = (ctypes.c_size_t * k)(*[b[1] for b in bufs])
+        # (the bytes objects themselves are read, not copies of them: they stay alive in `items` for the call)
+        ptrs = (ctypes.c_void_p * k)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value if b else None for _, b in items])
+        lens = (ctypes.c_size_t * k)(*[len(b) for _, b in items])
         status = (ctypes.c_int32 * k)()
         if lib().milzma_streams_write(self._h, k, idx, ptrs, lens, status) != OK:
             raise InfraError("milzma_streams_write: " + lib().milzma_streams_last_error(self._h).decode())

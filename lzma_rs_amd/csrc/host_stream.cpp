@@ -135,8 +135,10 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
       in_total += round_up(S->s[i].pending.size(), 64) + 64;
     }
     if (!pin_reserve(ctx, ctx->pin_in, in_total + 512) || !dev_reserve(ctx, ctx->in, in_total + 512)) return false;
-    for (uint32_t i : active)
+    parallel_for(active.size(), [&](size_t a) {
+      const uint32_t i = active[a];
       if (!S->s[i].pending.empty()) memcpy(static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off, S->s[i].pending.data(), S->s[i].pending.size());
+    });
     if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
         !hip_ok(ctx, hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_total, hipMemcpyHostToDevice, work_stream(ctx)), "H2D views"))
       return false;
@@ -238,11 +240,18 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
   }
   std::vector<uint32_t> active;
   std::vector<int32_t> st(k, MILZMA_OK);
+  // the bytes first, every stream's on its own (streams in Header / Data state keep them), on the host threads
+  parallel_for(k, [&](size_t j) {
+    One& o = S->s[idx[j]];
+    if (len[j] && (o.st == One::HEADER || o.st == One::DATA)) {
+      const uint8_t* p = static_cast<const uint8_t*>(data[j]);
+      o.pending.insert(o.pending.end(), p, p + len[j]);
+    }
+  });
   for (uint32_t j = 0; j < k; j++) {
     One& o = S->s[idx[j]];
     o.write_err.clear();
     if (len[j] == 0) continue;   // (write_all of nothing calls nobody: std::io::Write::write_all)
-    const uint8_t* p = static_cast<const uint8_t*>(data[j]);
     switch (o.st) {
       case One::FAILED:          // Stream.state is None: write() takes everything and does nothing (stream.rs:227-229, :324-325)
         break;
@@ -253,7 +262,6 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
         st[j] = MILZMA_IO_ERROR;
         break;
       case One::HEADER: {
-        o.pending.insert(o.pending.end(), p, p + len[j]);
         milzma_unit u;
         size_t hl = 0;
         milzma_output ho;
@@ -276,7 +284,6 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
         break;
       }
       case One::DATA:
-        o.pending.insert(o.pending.end(), p, p + len[j]);
         active.push_back(idx[j]);
         break;
     }
@@ -331,18 +338,26 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     return MILZMA_INFRA_ERROR;
   }
   int worst = MILZMA_OK;
-  std::vector<uint8_t> host;
-  for (uint32_t i = 0; i < S->n; i++) {
+  // Every stream's bytes go from its slice straight into its result buffer: page-locked buffers from the pool when a batch is large
+  // (the copies then run at link speed and nothing is copied twice), all copies queued on the work stream, one wait.
+  const bool pinned = S->n >= 64 && pinned_results_wanted();
+  std::vector<milzma_result> fin(S->n);
+  std::vector<uint8_t> has(S->n, 0);
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) {
+    for (uint32_t i = 0; i < S->n; i++) infra(ctx, &outs[i]);
+    return MILZMA_INFRA_ERROR;
+  }
+  parallel_for(S->n, [&](size_t ii) {   // (taking thousands of buffers from the pool -- or pinning them, the first time -- on the host threads)
+    const uint32_t i = uint32_t(ii);
     One& o = S->s[i];
     milzma_output* out = &outs[i];
     if (o.st == One::HEADER) {   // stream.rs:122-128
       if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");
-      out->in_consumed = 0;
-      continue;
+      return;
     }
     if (o.st == One::FAILED) {   // stream.rs:144-148
       out_fail(out, MILZMA_LZMA_ERROR, "can't finish stream because of previous write error");
-      continue;
+      return;
     }
     milzma_result r = S->res[i];
     const bool incomplete_ok =
@@ -353,15 +368,38 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
       r.out_flushed = r.out_len;
     }
     const size_t visible = size_t(std::min<uint64_t>(r.out_flushed, S->units[i].out_cap));
-    host.resize(visible);
-    if (visible && !hip_ok(ctx, hipMemcpy(host.data(), static_cast<const uint8_t*>(S->out.p) + S->units[i].out_off, visible, hipMemcpyDeviceToHost),
-                           "D2H output")) {
+    out->data = out_alloc(visible, pinned && visible >= 4096);
+    if (!out->data) {
+      out_fail(out, MILZMA_INFRA_ERROR, "out of memory");
+      return;
+    }
+    out->len = visible;
+    fin[i] = r;
+    has[i] = 1;
+  });
+  bool copies_ok = true;
+  for (uint32_t i = 0; i < S->n && copies_ok; i++)
+    if (has[i] && outs[i].len)
+      copies_ok = hip_ok(ctx, hipMemcpyAsync(outs[i].data, static_cast<const uint8_t*>(S->out.p) + S->units[i].out_off, outs[i].len, hipMemcpyDeviceToHost,
+                                             work_stream(ctx)),
+                         "D2H output");
+  copies_ok = hip_ok(ctx, hipStreamSynchronize(work_stream(ctx)), "hipStreamSynchronize") && copies_ok;
+  for (uint32_t i = 0; i < S->n; i++) {
+    if (!has[i]) {
+      if (outs[i].kind == MILZMA_INFRA_ERROR) worst = MILZMA_INFRA_ERROR;
+      continue;
+    }
+    milzma_output* out = &outs[i];
+    if (!copies_ok) {
+      milzma_free(out->data);
+      out->data = nullptr;
+      out->len = 0;
       infra(ctx, out);
       worst = MILZMA_INFRA_ERROR;
       continue;
     }
-    r.in_consumed = o.consumed;   // (what finish_stream adds the header to: the whole stream's reader position)
-    finish_stream(r, MILZMA_KIND_RAW_LZMA, host.data(), visible, o.hdr_len, out);
+    out->in_consumed = S->s[i].hdr_len + size_t(S->s[i].consumed);   // the whole stream's reader position
+    out->kind = milzma_result_message(&fin[i], MILZMA_KIND_RAW_LZMA, out->msg, sizeof out->msg);
   }
   return worst;
 }
