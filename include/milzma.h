@@ -420,6 +420,8 @@ uint32_t milzma_abi_version(void);
  *                          failed to fill whole buffer", unless allow_incomplete, which hands over everything decoded so far; after a
  *                          failed write: "lzma error: can't finish stream because of previous write error"), data = what the sink holds.
  *                          Once; afterwards only milzma_streams_close (which may also be called without finish).
+ * A milzma_streams is used by one thread at a time (like a context); different ones are independent.  An infrastructure failure of a
+ * write (MILZMA_INFRA_ERROR: a HIP error, no memory) leaves the batch unusable: close it.
  * Differences from the crate, all in WHEN and not in WHAT: the crate decodes a symbol as soon as 20 bytes are at hand OR a trial run
  * shows it complete within fewer; here the second case waits for the next write (or finish).  So an error inside the last 19 bytes of
  * everything written so far is reported one call later than by the crate, and Stream::get_output is not offered (the sink's contents

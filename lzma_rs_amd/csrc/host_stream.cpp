@@ -28,7 +28,6 @@ struct One {
   size_t hdr_len = 0;
   uint64_t consumed = 0;           // payload bytes the decoder has taken
   bool started = false;            // its unit has been launched (it owns an output slice)
-  bool marker_done = false;        // ended by its end marker / by the end of input: nothing more can be written to it
   std::string write_err;           // text of the io::Error of the write that failed
 };
 
@@ -99,6 +98,7 @@ static bool regrow(milzma_streams* S, const std::vector<std::pair<uint32_t, uint
 // Streams that run out of room get larger slices and go on until they need input (or end).  Updates pending / consumed / res.
 static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool last) {
   milzma_ctx* ctx = S->ctx;
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return false;   // (the calling thread may have been on another device)
   // slices for the streams that start now
   {
     std::vector<std::pair<uint32_t, uint64_t>> want;
@@ -241,13 +241,25 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
   std::vector<uint32_t> active;
   std::vector<int32_t> st(k, MILZMA_OK);
   // the bytes first, every stream's on its own (streams in Header / Data state keep them), on the host threads
+  std::atomic<int> no_memory{0};
   parallel_for(k, [&](size_t j) {
     One& o = S->s[idx[j]];
     if (len[j] && (o.st == One::HEADER || o.st == One::DATA)) {
       const uint8_t* p = static_cast<const uint8_t*>(data[j]);
-      o.pending.insert(o.pending.end(), p, p + len[j]);
+      try {   // (an exception must not leave a host thread)
+        o.pending.insert(o.pending.end(), p, p + len[j]);
+      } catch (const std::exception&) {
+        no_memory.store(1);
+      }
     }
   });
+  if (no_memory.load()) {   // some streams have taken their bytes, some have not: the batch cannot go on
+    S->finished = true;
+    ctx->err = "out of memory while buffering the written bytes: the streams are closed";
+    if (status)
+      for (uint32_t j = 0; j < k; j++) status[j] = MILZMA_INFRA_ERROR;
+    return MILZMA_INFRA_ERROR;
+  }
   for (uint32_t j = 0; j < k; j++) {
     One& o = S->s[idx[j]];
     o.write_err.clear();

@@ -20,6 +20,9 @@ from lzma_rs_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 
+# MILZMA_TEST_EXTRA_SEEDS=k: k more seeds per parametrized test (out-of-suite fuzz runs: profiles/r05_parity_fuzz.txt)
+EXTRA = [1000 + 37 * j for j in range(int(os.environ.get("MILZMA_TEST_EXTRA_SEEDS", "0")))]
+
 
 @pytest.fixture(scope="module")
 def ctx():
@@ -126,7 +129,7 @@ def _compare(res, outs, pos, comps, kinds, heads, refs):
         assert pos[i] + heads[i] == ref.in_consumed, (i, pos[i] + heads[i], ref.in_consumed, len(comps[i]))
 
 
-@pytest.mark.parametrize("seed", [81, 181, 281])
+@pytest.mark.parametrize("seed", [81, 181, 281] + EXTRA)
 def test_fed_raw_streams_of_every_class(ctx, seed):
     """RAW .lzma payloads: every property class of the loop's four variants (lc + lp >= 4 with their rows in the slab), known and unknown
     sizes, a truncated and a damaged one, text / zeros / random data; pieces of 1 .. 3000 bytes, the views moved to a new place with a new
@@ -159,7 +162,7 @@ def test_fed_raw_streams_of_every_class(ctx, seed):
     assert sum(1 for r in refs if not r.ok) >= 3
 
 
-@pytest.mark.parametrize("seed", [82, 182, 282])
+@pytest.mark.parametrize("seed", [82, 182, 282] + [e + 1 for e in EXTRA])
 def test_fed_lzma2_units_with_every_packet_kind(ctx, seed):
     """LZMA2 units: liblzma's streams (compressed chunks, stored chunks for random data) and hand-made packet sequences (every control
     byte, property switches up to lc + lp = 4, dictionary resets, stored chunks, chunks a few symbols long); the views end inside packet
@@ -184,7 +187,7 @@ def test_fed_lzma2_units_with_every_packet_kind(ctx, seed):
     assert counts["input_parks"] > 300, counts
 
 
-@pytest.mark.parametrize("seed", [83, 183, 283])
+@pytest.mark.parametrize("seed", [83, 183, 283] + [e + 2 for e in EXTRA])
 def test_fed_input_and_growable_output_together(ctx, seed):
     """Both parking reasons in one batch: slices of a few hundred bytes and pieces of a few hundred bytes, RAW and LZMA2 units.  A unit
     parked for room by a FEED call resumes on a re-based view like one parked for input."""

@@ -19,6 +19,9 @@ from lzma_rs_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 
+# MILZMA_TEST_EXTRA_SEEDS=k: k more seeds for the random schedules (out-of-suite fuzz runs: profiles/r05_parity_fuzz.txt)
+EXTRA = [2000 + 41 * j for j in range(int(os.environ.get("MILZMA_TEST_EXTRA_SEEDS", "0")))]
+
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EMPTY = b"\x5d\x00\x00\x80\x00\xff\xff\xff\xff\xff\xff\xff\xff\x00\x83\xff\xfb\xff\xff\xc0\x00\x00\x00"
 WRITE_ZERO = "failed to write whole buffer"
@@ -162,7 +165,7 @@ def test_fixture_files_in_chunks(ctx):   # tests/lzma.rs:116-131: CHUNK_SIZES
     assert compare(comps, scheds, errs, decs, what="fixtures") == 0 and all(d.ok for d in decs)
 
 
-@pytest.mark.parametrize("seed", [91, 191])
+@pytest.mark.parametrize("seed", [91, 191] + EXTRA)
 def test_random_chunkings_of_good_and_bad_streams(ctx, seed):
     rng = random.Random(seed)
     comps = []
