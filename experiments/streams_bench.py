@@ -48,7 +48,7 @@ def main():
     for rep in range(4):
         t0 = time.perf_counter()
         h = ctypes.c_void_p()
-        assert L.milzma_streams_open(ctx._h, n, None, ctypes.byref(h)) == M.OK
+        assert L.milzma_streams_open(ctx._h, M.KIND_RAW_LZMA, n, None, ctypes.byref(h)) == M.OK
         for parts, idx, ptrs, lens, status in calls:
             assert L.milzma_streams_write(h, n, idx, ptrs, lens, status) == M.OK and not any(status)
         t1 = time.perf_counter()

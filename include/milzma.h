@@ -404,8 +404,13 @@ uint32_t milzma_abi_version(void);
  * A milzma_streams is n of them over one GPU (a context of its own behind `ctx`'s device): a write call appends bytes to any of the
  * streams and runs ONE launch in which every stream that got bytes takes another turn (fed input, MILZMA_DECODE_FEED: streams whose
  * header has just become complete start in that launch, the others resume where they parked).  Output stays on the device until finish.
- *   milzma_streams_open    n x Stream::new_with_options (stream.rs:88-101); options: n entries (unpacked_size mode, memlimit,
- *                          allow_incomplete) or NULL for Options::default().
+ *   milzma_streams_open    kind = MILZMA_KIND_RAW_LZMA: n x Stream::new_with_options (stream.rs:88-101) -- .lzma files, header first;
+ *                          options: n entries (unpacked_size mode, memlimit, allow_incomplete) or NULL for Options::default().
+ *                          kind = MILZMA_KIND_LZMA2: n raw LZMA2 streams fed the same way (the crate has no such type; what it gives a
+ *                          binding is lzma2_decompress over a reader that shows its input piece by piece -- the verdict and the reader
+ *                          position of Lzma2Decoder::decompress, src/decode/lzma2.rs:52-82 -- without reading ahead; options ignored).
+ *                          A stream of either kind that has ENDED (declared size reached, LZMA2 end byte read) takes no more bytes:
+ *                          WriteZero, and finish's in_consumed says where it ended.
  *   milzma_streams_write   io::Write::write_all (over Stream::write, stream.rs:223-326) for k of the streams: data[j] / len[j] go to
  *                          stream idx[j] (a stream at most once per call).  status[j] (optional): MILZMA_OK, or MILZMA_IO_ERROR when that
  *                          write_all returns Err -- milzma_streams_write_error(s, idx[j]) is the io::Error's text: a fatal header error
@@ -422,15 +427,26 @@ uint32_t milzma_abi_version(void);
  *                          Once; afterwards only milzma_streams_close (which may also be called without finish).
  * A milzma_streams is used by one thread at a time (like a context); different ones are independent.  An infrastructure failure of a
  * write (MILZMA_INFRA_ERROR: a HIP error, no memory) leaves the batch unusable: close it.
- * Differences from the crate, all in WHEN and not in WHAT: the crate decodes a symbol as soon as 20 bytes are at hand OR a trial run
- * shows it complete within fewer; here the second case waits for the next write (or finish).  So an error inside the last 19 bytes of
- * everything written so far is reported one call later than by the crate, and Stream::get_output is not offered (the sink's contents
- * between calls depend on exactly that).  And nothing is decoded BEHIND AN END MARKER: the crate's loop merely leaves at the marker, so
+ * The crate decodes a symbol as soon as 20 bytes are at hand OR a trial run shows it complete within fewer (lzma.rs:455-516); so does
+ * this implementation -- the tail of every write's data is decoded as far as its symbols are complete (a second pass over the tail
+ * from a saved state, decode_fast_asm.hip.h) -- and a failed write is the very write the crate fails.  Two differences remain.  For
+ * streams with lc + lp >= 4 (literal rows in device memory, which a saved state does not cover) the tail waits for the next write: an
+ * error inside the last 19 bytes written so far is reported one call later (or by finish), never differently.  And nothing is decoded
+ * BEHIND AN END MARKER: the crate's loop merely leaves at the marker, so
  * bytes written to the stream in a later call are decoded on from the marker's state (here: WriteZero), and a finish() that finds a
  * provided size not reached trips over the marker's distance ("Match distance 4294967296 is beyond dictionary size ..."; here: the
  * one-shot call's "Expected unpacked size of {} but decompressed to {}"). */
 typedef struct milzma_streams milzma_streams;
-int milzma_streams_open(milzma_ctx *ctx, uint32_t n, const milzma_options *options, milzma_streams **out);
+/* or-ed into milzma_streams_open's `kind`: READER mode -- the streams stand for the crate's one-shot lzma_decompress / lzma2_decompress over
+ * a `BufRead` that shows its input piece by piece (a BufReader over a socket or a large file): the pieces are written as they are shown,
+ * and milzma_streams_finish hands over what the ONE-SHOT call would -- a failed decode's own error with the bytes written before it,
+ * not Stream::finish's "previous write error"; a header that never became complete as "header too short: ..." -- with in_consumed the
+ * reader position of the whole stream.  A write that fails or reports WriteZero tells the caller to stop showing input and finish:
+ * in_consumed minus the bytes of the pieces written BEFORE that one is how much of the last piece the reader is to consume
+ * (integration/rust/src/lib.rs `run_fed`).  Exact for every stream whose literal rows are register resident (lc + lp <= 3); with
+ * lc + lp >= 4 up to 19 bytes behind a stream's end may have been taken with an earlier piece. */
+#define MILZMA_STREAMS_AS_READER 0x100u
+int milzma_streams_open(milzma_ctx *ctx, uint32_t kind, uint32_t n, const milzma_options *options, milzma_streams **out);
 int milzma_streams_write(milzma_streams *s, uint32_t k, const uint32_t *idx, const void *const *data, const size_t *len, int32_t *status);
 const char *milzma_streams_write_error(const milzma_streams *s, uint32_t stream);
 int milzma_streams_finish(milzma_streams *s, milzma_output *outs);

@@ -41,6 +41,8 @@ pub const MILZMA_DECODE_GROW: u32 = 1;
 pub const MILZMA_DECODE_RESUME: u32 = 2;
 /// fed input: every unit's (in_off, in_len) is a view of a stream that goes on behind it (include/milzma.h)
 pub const MILZMA_DECODE_FEED: u32 = 4;
+/// or-ed into `milzma_streams_open`'s kind: finish hands over what the one-shot call over a reader would (include/milzma.h)
+pub const MILZMA_STREAMS_AS_READER: u32 = 0x100;
 pub const MILZMA_PATH_STREAMED: u32 = 1;
 pub const MILZMA_PATH_TWO_PART_INPUT: u32 = 2;
 pub const MILZMA_PATH_CLASSIC: u32 = 4;
@@ -322,7 +324,7 @@ extern "C" {
         outs: *mut milzma_output,
     ) -> c_int;
     // push-mode decoding: Stream (feature `stream`) for a batch of streams
-    pub fn milzma_streams_open(ctx: *mut milzma_ctx, n: u32, options: *const milzma_options, out: *mut *mut milzma_streams) -> c_int;
+    pub fn milzma_streams_open(ctx: *mut milzma_ctx, kind: u32, n: u32, options: *const milzma_options, out: *mut *mut milzma_streams) -> c_int;
     pub fn milzma_streams_write(
         s: *mut milzma_streams,
         k: u32,

@@ -37,6 +37,7 @@ ST_OUT_FULL = 32
 PARKED = 1                      # Result.err_a of a unit that stopped for room and can be resumed (MILZMA_PARKED)
 DECODE_GROW, DECODE_RESUME, DECODE_FEED = 1, 2, 4   # flags of decode_units_ex (MILZMA_DECODE_*)
 ST_NEED_INPUT = 37              # ... DECODE_FEED: parked within 20 bytes of the end of its input view (err_a == PARKED)
+STREAMS_AS_READER = 0x100       # or-ed into Streams' kind: finish() = the verdict of the one-shot call over a reader (MILZMA_STREAMS_AS_READER)
 KIND_LAST_VIEW = 0x80           # or-ed into Unit.kind in a DECODE_FEED call: the view ends where the stream ends
 
 
@@ -238,7 +239,7 @@ def lib():
     L.milzma_crc32.argtypes = [vp, sz]
     L.milzma_crc64.restype = u64
     L.milzma_crc64.argtypes = [vp, sz]
-    L.milzma_streams_open.argtypes = [vp, u32, ctypes.POINTER(_COptions), ctypes.POINTER(vp)]
+    L.milzma_streams_open.argtypes = [vp, u32, u32, ctypes.POINTER(_COptions), ctypes.POINTER(vp)]
     L.milzma_streams_write.argtypes = [vp, u32, ctypes.POINTER(u32), ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_int32)]
     L.milzma_streams_write_error.restype = ctypes.c_char_p
     L.milzma_streams_write_error.argtypes = [vp, u32]
@@ -590,7 +591,7 @@ class Streams:
     the text of the io::Error of a failed write (empty dict: every write succeeded); finish() is Stream::finish for every stream: a list
     of Decoded."""
 
-    def __init__(self, ctx, n, options=None):
+    def __init__(self, ctx, n, options=None, kind=KIND_RAW_LZMA):
         self.n = n
         self._h = ctypes.c_void_p()
         copts = None
@@ -598,7 +599,7 @@ class Streams:
             opts = options if isinstance(options, (list, tuple)) else [options] * n
             assert len(opts) == n
             copts = (_COptions * n)(*[_c_options(o) for o in opts])
-        if lib().milzma_streams_open(ctx._h, n, copts, ctypes.byref(self._h)) != OK:
+        if lib().milzma_streams_open(ctx._h, kind, n, copts, ctypes.byref(self._h)) != OK:
             raise InfraError("milzma_streams_open: " + ctx.last_error())
 
     def write(self, pieces):
@@ -631,6 +632,26 @@ class Streams:
             self.close()
         except Exception:
             pass
+
+
+def decompress_reader(ctx, kind, data, bufsize, options=None):
+    """The one-shot `lzma_decompress` / `lzma2_decompress` over an `io::BufRead` whose buffer holds `bufsize` bytes -- a BufReader over a
+    socket or a large file -- the way integration/rust/src/lib.rs `run_fed` does it: every `fill_buf` view is written to a push-mode
+    stream in READER mode and consumed; a write that fails (or reports WriteZero: the stream has ended) ends the loop, and finish says how
+    much of the last view the decoder used.  Returns (Decoded, reader position afterwards)."""
+    s = Streams(ctx, 1, options, kind=kind | STREAMS_AS_READER)
+    pos = fed = 0
+    while True:
+        view = bytes(data[pos:pos + bufsize])      # fill_buf
+        if not view:
+            break
+        if s.write({0: view}):
+            break                                  # (not consumed: finish says how much of it belongs to the stream)
+        pos += len(view)                           # consume
+        fed += len(view)
+    d = s.finish()[0]
+    s.close()
+    return d, pos + max(0, d.in_consumed - fed)
 
 
 _default_ctx = None

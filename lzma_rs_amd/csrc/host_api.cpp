@@ -370,17 +370,17 @@ extern "C" int milzma_decode_units_wait(milzma_ctx* ctx, milzma_result* results)
 
 
 // ---- push-mode streams (host_stream.cpp) -----------------------------------------------------------------------------------------
-MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out);
+MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out);
 MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len, int32_t* status);
 MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* outs);
 MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S);
 MILZMA_HIDDEN const char* milzma_streams_write_error_impl(const milzma_streams* S, uint32_t stream);
 MILZMA_HIDDEN const char* milzma_streams_last_error_impl(const milzma_streams* S);
 
-extern "C" int milzma_streams_open(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out) {
+extern "C" int milzma_streams_open(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out) {
   begin_call(ctx);
   try {
-    return milzma_streams_open_impl(ctx, n, options, out);
+    return milzma_streams_open_impl(ctx, kind, n, options, out);
   } catch (const std::exception& e) {
     if (ctx) ctx->err = std::string("host exception: ") + e.what();
     return MILZMA_INFRA_ERROR;

@@ -29,13 +29,18 @@ struct One {
   uint64_t consumed = 0;           // payload bytes the decoder has taken
   bool started = false;            // its unit has been launched (it owns an output slice)
   std::string write_err;           // text of the io::Error of the write that failed
+  // reader mode (MILZMA_STREAMS_AS_READER): what the failed decode itself said, for finish to hand over instead of Stream::finish's
+  // "previous write error"
+  bool has_fail = false;
+  milzma_result fail;              // a decode error (with the reader position of the whole stream in in_consumed)
+  milzma_output header_fail;       // a fatal header error
 };
 
 // the io::Error a failed Stream::write returns for a decode error: io::Error::new(Other, format!("{:?}", error)) (stream.rs:343-347);
 // Debug of error::Error::LzmaError(String) is LzmaError("...")
-std::string debug_lzma_error(const milzma_result& r) {
+std::string debug_lzma_error(const milzma_result& r, uint32_t kind) {
   char msg[400];
-  milzma_result_message(&r, MILZMA_KIND_RAW_LZMA, msg, sizeof msg);
+  milzma_result_message(&r, kind, msg, sizeof msg);
   const char* m = strchr(msg, ':');
   return std::string("LzmaError(\"") + (m ? m + 2 : msg) + "\")";
 }
@@ -51,6 +56,8 @@ struct milzma_streams {
   DevBuf out;                  // the streams' output slices
   size_t out_used = 0;
   bool finished = false;
+  uint32_t kind = MILZMA_KIND_RAW_LZMA;   // MILZMA_KIND_RAW_LZMA: .lzma files (header first, as the crate's Stream); MILZMA_KIND_LZMA2: raw LZMA2 streams
+  bool as_reader = false;      // finish hands over what the ONE-SHOT call would (lzma_decompress over a reader that shows its input piece by piece)
 };
 
 MILZMA_HOST_NS_BEGIN
@@ -118,7 +125,7 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
         memset(&S->res[w.first], 0, sizeof(milzma_result));
       }
       if (!regrow(S, want)) return false;
-      for (const auto& w : want) S->units[w.first].kind = MILZMA_KIND_RAW_LZMA | MILZMA_KIND_START;   // (marks this round only)
+      for (const auto& w : want) S->units[w.first].kind = uint8_t(S->kind | MILZMA_KIND_START);   // (marks this round only)
     }
   }
   for (int round = 0; !active.empty(); round++) {
@@ -182,9 +189,15 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
 
 MILZMA_HOST_NS_END
 
-MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t n, const milzma_options* options, milzma_streams** out) {
+MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out) {
   if (!ctx || !out) return MILZMA_INFRA_ERROR;
   *out = nullptr;
+  const bool as_reader = (kind & MILZMA_STREAMS_AS_READER) != 0;
+  kind &= ~uint32_t(MILZMA_STREAMS_AS_READER);
+  if (kind != MILZMA_KIND_RAW_LZMA && kind != MILZMA_KIND_LZMA2) {
+    ctx->err = "push-mode streams: kind must be MILZMA_KIND_RAW_LZMA (.lzma files) or MILZMA_KIND_LZMA2";
+    return MILZMA_INFRA_ERROR;
+  }
   if (!(ctx->use_fast && ctx->fast_spill)) {
     ctx->err = "push-mode streams need the asm kernel's launch classes (MILZMA_KERNEL / MILZMA_SPILL = generic set)";
     return MILZMA_INFRA_ERROR;
@@ -196,6 +209,8 @@ MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t n, const mi
   }
   auto* S = new milzma_streams();
   S->ctx = own;
+  S->kind = kind;
+  S->as_reader = as_reader;
   S->n = n;
   S->s.resize(n);
   S->units.resize(n);
@@ -268,12 +283,35 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
       case One::FAILED:          // Stream.state is None: write() takes everything and does nothing (stream.rs:227-229, :324-325)
         break;
       case One::DONE:
+        if (S->as_reader && S->kind == MILZMA_KIND_RAW_LZMA && S->units[idx[j]].unpacked_size == MILZMA_SIZE_UNKNOWN &&
+            S->res[idx[j]].status == MILZMA_ST_OK) {
+          // reader mode, a stream that ended with its END MARKER where a piece ended -- and the reader shows more: the one-shot call asks
+          // the reader itself whether it is at its end (is_finished_ok, rangecoder.rs:49-52) and fails (lzma.rs:378-380)
+          milzma_result r = S->res[idx[j]];
+          r.status = MILZMA_ST_MARKER_TRAILING;
+          r.out_flushed = r.out_len / S->units[idx[j]].dict_size * S->units[idx[j]].dict_size;   // (what the ring had flushed: lzbuffer.rs:264-267)
+          o.fail = r;
+          o.has_fail = true;
+          o.write_err = debug_lzma_error(r, S->kind);
+          o.st = One::FAILED;
+          st[j] = MILZMA_IO_ERROR;
+          break;
+        }
         // the declared size is reached: write() takes nothing, write_all reports ErrorKind::WriteZero (lzma.rs:441-445; tests/lzma.rs:71-87).
         // (Behind an end marker the reference would decode on from the marker's state; that is not followed: same answer.)
         o.write_err = "failed to write whole buffer";
         st[j] = MILZMA_IO_ERROR;
         break;
       case One::HEADER: {
+        if (S->kind == MILZMA_KIND_LZMA2) {   // no header: the stream begins with its first packet
+          milzma_unit u;
+          memset(&u, 0, sizeof u);
+          u.kind = MILZMA_KIND_LZMA2;
+          S->units[idx[j]] = u;
+          o.st = One::DATA;
+          active.push_back(idx[j]);
+          break;
+        }
         milzma_unit u;
         size_t hl = 0;
         milzma_output ho;
@@ -282,6 +320,7 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
         if (hr != MILZMA_OK) {                      // fatal: LzmaError(s) => io::Error::new(Other, s) (stream.rs:291-299)
           const char* m = strchr(ho.msg, ':');
           o.write_err = m ? m + 2 : ho.msg;
+          o.header_fail = ho;
           o.st = One::FAILED;
           st[j] = MILZMA_IO_ERROR;
           break;
@@ -320,7 +359,9 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
         st[j] = MILZMA_IO_ERROR;
       }
     } else {
-      o.write_err = debug_lzma_error(r);
+      o.write_err = debug_lzma_error(r, S->kind);
+      o.fail = r;
+      o.has_fail = true;
       o.st = One::FAILED;
       st[j] = MILZMA_IO_ERROR;
     }
@@ -363,15 +404,28 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     const uint32_t i = uint32_t(ii);
     One& o = S->s[i];
     milzma_output* out = &outs[i];
-    if (o.st == One::HEADER) {   // stream.rs:122-128
-      if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");
+    if (o.st == One::HEADER) {
+      if (S->as_reader) {   // the one-shot call on the few bytes there are: "header too short: ...", "LZMA stream too short: ..."
+        if (S->kind == MILZMA_KIND_LZMA2)
+          milzma_lzma2_decompress_impl(ctx, o.pending.data(), o.pending.size(), out);
+        else
+          milzma_lzma_decompress_impl(ctx, o.pending.data(), o.pending.size(), &o.opt, out);
+        return;
+      }
+      if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");   // stream.rs:122-128
       return;
     }
-    if (o.st == One::FAILED) {   // stream.rs:144-148
-      out_fail(out, MILZMA_LZMA_ERROR, "can't finish stream because of previous write error");
+    if (o.st == One::FAILED && !(S->as_reader && o.has_fail)) {
+      if (S->as_reader) {   // the header's own error, reader position included
+        *out = o.header_fail;
+        out->data = nullptr;
+        out->len = 0;
+        return;
+      }
+      out_fail(out, MILZMA_LZMA_ERROR, "can't finish stream because of previous write error");   // stream.rs:144-148
       return;
     }
-    milzma_result r = S->res[i];
+    milzma_result r = o.st == One::FAILED ? o.fail : S->res[i];
     const bool incomplete_ok =
         o.opt.allow_incomplete && (r.status == MILZMA_ST_INPUT_EOF || r.status == MILZMA_ST_MATCH_DIST_DICT || r.status == MILZMA_ST_MATCH_DIST_OUT ||
                                    r.status == MILZMA_ST_SIZE_MISMATCH);
@@ -411,7 +465,7 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
       continue;
     }
     out->in_consumed = S->s[i].hdr_len + size_t(S->s[i].consumed);   // the whole stream's reader position
-    out->kind = milzma_result_message(&fin[i], MILZMA_KIND_RAW_LZMA, out->msg, sizeof out->msg);
+    out->kind = milzma_result_message(&fin[i], S->kind, out->msg, sizeof out->msg);
   }
   return worst;
 }

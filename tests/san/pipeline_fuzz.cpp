@@ -467,7 +467,7 @@ bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool) {
     for (orc_result& w : want) orc_free(w.out);
     return true;
   }
-  if (milzma_streams_open(ctx, n, nullptr, &S) != MILZMA_OK) {
+  if (milzma_streams_open(ctx, MILZMA_KIND_RAW_LZMA, n, nullptr, &S) != MILZMA_OK) {
     printf("INFRA streams_open: %s\n", milzma_last_error(ctx));
     ok = false;
   }

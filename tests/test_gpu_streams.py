@@ -91,18 +91,26 @@ def compare(comps, schedules, errs, decs, options=None, what="", skip=()):
         o_fail = [e for e in o_errs if e[1] != WRITE_ZERO]
         g_fail = [e for e in errs[i] if e[1] != WRITE_ZERO]
         d = decs[i]
+        # (streams with lc + lp >= 4 keep their literal rows in device memory: the tail of a write's data is not tried symbol by symbol
+        #  for them -- include/milzma.h --, so an error inside the last 19 bytes may be reported a call later than by the crate)
+        rows_in_hbm = len(comp) > 0 and comp[0] < 225 and (comp[0] % 9) + (comp[0] // 9) % 5 >= 4
         if not o_fail and not g_fail:
             assert (d.kind, d.msg) == (o_fin.kind, o_fin.msg), (what, i, d.msg, o_fin.msg)
             if o_fin.ok:
                 assert d.data == o_fin.out, (what, i, len(d.data), len(o_fin.out))
         elif o_fail and g_fail:
             assert g_fail[0][1] == o_fail[0][1], (what, i, g_fail[0], o_fail[0])
-            assert g_fail[0][0] >= o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # never earlier than the crate
-            lagged += g_fail[0][0] > o_fail[0][0]
+            if rows_in_hbm:
+                assert g_fail[0][0] >= o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # never earlier than the crate
+                lagged += g_fail[0][0] > o_fail[0][0]
+            else:
+                assert g_fail[0][0] == o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # in the very call the crate reports it in
+
             assert (d.kind, d.msg) == (o_fin.kind, o_fin.msg) and "previous write error" in d.msg, (what, i, d.msg)
         elif o_fail:
-            # the crate reported it in a write, by a trial run on the last bytes; here it comes out of finish -- the same error
+            # lc + lp >= 4 only: the crate reported it in a write, by a trial run on the last bytes; here it comes out of finish -- the same error
             inner = o_fail[0][1]
+            assert rows_in_hbm, (what, i, "the crate's write fails, this one's does not", o_fail[0], d.msg)
             assert inner.startswith('LzmaError("') and d.kind == M.LZMA_ERROR and d.msg == "lzma error: " + inner[len('LzmaError("'):-2], (what, i, d.msg, inner)
             lagged += 1
         else:
