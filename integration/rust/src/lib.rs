@@ -25,8 +25,10 @@
 //!   a buffer boundary of a `BufReader` over a large file (an unknown-size `.lzma` stream is "finished" when the reader is
 //!   at EOF with `code == 0`, src/decode/lzma.rs:446-455: a view cut there would be accepted short).  The view is
 //!   consumed and the reader probed with another `fill_buf`: empty = that was the end, the verdict stands; otherwise
-//!   everything is read and decoded again, and the reader is left at ITS end (`io::BufRead` has no un-read) -- the one
-//!   difference from the streaming reference, and only for readers that cannot show their input at once.
+//!   `.lzma` and LZMA2 input is FED (round 5, `run_fed`): the views go to a push-mode stream as the reader shows them and the
+//!   reader ends up exactly where the reference's would (right behind a stream of known size, at the failing byte of a
+//!   damaged one).  Only `.xz` still reads everything and decodes again, leaving such a reader at ITS end (`io::BufRead`
+//!   has no un-read; the container's Index sits at the end of the file).
 //! `*_batch` functions take slices and have no such caveat.
 //!
 //! NOTE: written without a Rust toolchain (the build image has none); never compiled.  README.md: how to build and
@@ -272,6 +274,67 @@ fn run<R: io::BufRead, W: io::Write>(
     deliver(&mut out, input, true, output)
 }
 
+/// `run` for the two entry points whose decoder can be FED (`.lzma`, LZMA2; round 5): if the first view is not the whole input, the
+/// views are written to a push-mode stream in READER mode as `fill_buf` shows them (`MILZMA_STREAMS_AS_READER`, include/milzma.h) --
+/// nothing is read twice, nothing is decoded twice, and the reader is left exactly where the reference's would stand: right behind a
+/// stream of known size or an LZMA2 end byte, at the failing byte of a damaged one.  (`tests/test_gpu_reader.py` runs this loop --
+/// `lzma_rs_amd.decompress_reader` -- for buffers of 1 byte to everything against the oracle.)
+fn run_fed<R: io::BufRead, W: io::Write>(
+    ctx: &Context,
+    kind: u32,
+    options: Option<&decompress::Options>,
+    input: &mut R,
+    output: &mut W,
+    one_shot: impl Fn(&[u8], &mut ffi::milzma_output),
+) -> error::Result<()> {
+    // the common case first: a reader that shows everything at once is decoded by the one-shot call, as before
+    let first = input.fill_buf()?.to_vec();
+    let mut out = empty_output();
+    one_shot(&first, &mut out);
+    if out.in_consumed < first.len() {
+        return deliver(&mut out, input, false, output);
+    }
+    // the decoder ran to the end of the view: the reader's end, or only its buffer's?
+    input.consume(first.len());
+    if input.fill_buf()?.is_empty() {
+        return deliver(&mut out, input, true, output);
+    }
+    release(&mut out);
+    // only its buffer's: from here on the views are fed, the first one (consumed already, kept in `first`) ahead of what the reader shows next
+    let opts: Vec<decompress::Options> = options.map(|o| vec![*o]).unwrap_or_default();
+    let mut raw = ptr::null_mut();
+    let copts: Vec<ffi::milzma_options> = opts.iter().map(c_options).collect();
+    let rc = unsafe {
+        ffi::milzma_streams_open(ctx.raw, kind | ffi::MILZMA_STREAMS_AS_READER, 1, if copts.is_empty() { ptr::null() } else { copts.as_ptr() }, &mut raw)
+    };
+    if rc != ffi::MILZMA_OK {
+        return Err(infra("milzma_streams_open", unsafe { ffi::milzma_last_error(ctx.raw) }));
+    }
+    let mut s = Streams { raw, n: 1 };
+    let mut fed = first.len(); // bytes of the views consumed so far
+    // (the one-shot call got through all of `first`: neither an end nor an error lies strictly inside it)
+    let mut more = s.write(&[(0, &first)])?.pop().expect("one piece").is_ok();
+    while more {
+        let view = input.fill_buf()?;
+        if view.is_empty() {
+            break;
+        }
+        let n = view.len();
+        let wrote = s.write(&[(0, view)])?.pop().expect("one piece");
+        if wrote.is_err() {
+            more = false; // the stream ended or failed inside (or right in front of) this view: finish says where; nothing of it is consumed yet
+        } else {
+            input.consume(n);
+            fed += n;
+        }
+    }
+    let d = s.finish().pop().expect("one stream");
+    input.consume(d.in_consumed.saturating_sub(fed));
+    let wrote = output.write_all(&d.data).and_then(|_| output.flush());
+    wrote?;
+    d.result
+}
+
 fn release(out: &mut ffi::milzma_output) {
     if !out.data.is_null() {
         unsafe { ffi::milzma_free(out.data as *mut _) };
@@ -325,7 +388,8 @@ pub fn lzma_decompress_with_options<R: io::BufRead, W: io::Write>(
 ) -> error::Result<()> {
     let opt = c_options(options);
     with_default_ctx(|ctx| {
-        run(input, output, |bytes, out| unsafe {
+        // everything in the first view (a slice, a Cursor, a small file): the one-shot call; else piece by piece (`run_fed`)
+        run_fed(ctx, ffi::MILZMA_KIND_RAW_LZMA as u32, Some(options), input, output, |bytes, out| unsafe {
             ffi::milzma_lzma_decompress(ctx.raw, bytes.as_ptr(), bytes.len(), &opt, out);
         })
     })
@@ -334,7 +398,7 @@ pub fn lzma_decompress_with_options<R: io::BufRead, W: io::Write>(
 /// Decompress LZMA2 data with default options (src/lib.rs:83-88).
 pub fn lzma2_decompress<R: io::BufRead, W: io::Write>(input: &mut R, output: &mut W) -> error::Result<()> {
     with_default_ctx(|ctx| {
-        run(input, output, |bytes, out| unsafe {
+        run_fed(ctx, ffi::MILZMA_KIND_LZMA2 as u32, None, input, output, |bytes, out| unsafe {
             ffi::milzma_lzma2_decompress(ctx.raw, bytes.as_ptr(), bytes.len(), out);
         })
     })
