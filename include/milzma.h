@@ -177,10 +177,13 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *                         the parked states stay -- and takes the launch class from its own record, not from `results`.
  *   MILZMA_DECODE_FEED    (implies GROW) fed input -- the reference's streaming front end (`impl Write for Stream`, src/decode/stream.rs:223-283:
  *                         the caller hands the compressed bytes over piece by piece; lzma.rs:435-524 `process_mode(Partial)` decodes
- *                         a symbol only while MAX_REQUIRED_INPUT = 20 bytes are at hand or a trial run shows that fewer suffice).  Every unit's (in_off, in_len) is a VIEW: the bytes of its
- *                         stream that are on the device so far.  A unit that comes within 20 bytes of its view's end stops at a
- *                         symbol boundary (an LZMA2 unit also: in front of a packet header or a stored chunk that is not inside the
- *                         view) and is parked with (MILZMA_ST_NEED_INPUT, err_a = MILZMA_PARKED, in_consumed = bytes of THIS view it
+ *                         a symbol only while MAX_REQUIRED_INPUT = 20 bytes are at hand or a trial run shows that fewer suffice).
+ *                         Every unit's (in_off, in_len) is a VIEW: the bytes of its stream that are on the device so far.  A unit
+ *                         decodes what is COMPLETE in its view -- like the reference: every symbol while 20 bytes are left, then
+ *                         the symbols of the tail as far as they fit (units with lc + lp >= 4 leave the tail alone) -- and stops at
+ *                         the symbol boundary in front of the first one that is not (an LZMA2 unit also: in front of a packet header
+ *                         or a stored chunk that is not inside the view); fewer than 20 bytes are left unused then, and they belong
+ *                         to that symbol or packet.  It is parked with (MILZMA_ST_NEED_INPUT, err_a = MILZMA_PARKED, in_consumed = bytes of THIS view it
  *                         has used, out_len = bytes produced so far).  EVERY unit a FEED call parks -- for input or, as under GROW,
  *                         for room (MILZMA_ST_OUT_FULL) -- is resumed (RESUME | FEED, or plain RESUME when no stream has more to
  *                         come) with a descriptor whose view starts at its first unused byte: the bytes from in_off + in_consumed

@@ -524,7 +524,7 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
         const uint64_t least = std::max<uint32_t>(1u, ctx->slice_quantum / 4u * 3u);  // (a turn is 0.75 .. 1.5 quanta)
         for (uint32_t k = 0; k < m; k++) {
           const uint64_t cap_k = ctx->pend_units[order[i + k]].out_cap;
-          entries += cap_k / least + 2 + (feed ? 2 : 0);   // (fed input: a view's tail is queued once more for its second pass)
+          entries += cap_k / least + 2;
           longest = std::max(longest, cap_k);
         }
         const size_t ctx_bytes = slice_ctx_bytes() * ctx->pend_n;  // (indexed by unit, not by launch position)
