@@ -405,13 +405,7 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     One& o = S->s[i];
     milzma_output* out = &outs[i];
     if (o.st == One::HEADER) {
-      if (S->as_reader) {   // the one-shot call on the few bytes there are: "header too short: ...", "LZMA stream too short: ..."
-        if (S->kind == MILZMA_KIND_LZMA2)
-          milzma_lzma2_decompress_impl(ctx, o.pending.data(), o.pending.size(), out);
-        else
-          milzma_lzma_decompress_impl(ctx, o.pending.data(), o.pending.size(), &o.opt, out);
-        return;
-      }
+      if (S->as_reader) return;   // (done below, one after the other: it uses the context)
       if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");   // stream.rs:122-128
       return;
     }
@@ -443,6 +437,15 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     fin[i] = r;
     has[i] = 1;
   });
+  if (S->as_reader)   // a stream that never got past its header: the one-shot call on the few bytes there are ("header too short: ...",
+    for (uint32_t i = 0; i < S->n; i++)   //  "LZMA stream too short: ...") -- on the context, so not on the host threads above
+      if (S->s[i].st == One::HEADER) {
+        One& o = S->s[i];
+        if (S->kind == MILZMA_KIND_LZMA2)
+          milzma_lzma2_decompress_impl(ctx, o.pending.data(), o.pending.size(), &outs[i]);
+        else
+          milzma_lzma_decompress_impl(ctx, o.pending.data(), o.pending.size(), &o.opt, &outs[i]);
+      }
   bool copies_ok = true;
   for (uint32_t i = 0; i < S->n && copies_ok; i++)
     if (has[i] && outs[i].len)
