@@ -26,8 +26,9 @@ EXTRA = [1000 + 37 * j for j in range(int(os.environ.get("MILZMA_TEST_EXTRA_SEED
 
 @pytest.fixture(scope="module")
 def ctx():
-    for k in ("MILZMA_KERNEL", "MILZMA_SPILL", "MILZMA_SLICE"):
-        os.environ.pop(k, None)
+    if os.environ.get("MILZMA_TEST_KEEP_ENV") != "1":   # (stress runs keep MILZMA_SLICE=2 / MILZMA_QUANTUM: every unit parked at every quantum)
+        for k in ("MILZMA_KERNEL", "MILZMA_SPILL", "MILZMA_SLICE"):
+            os.environ.pop(k, None)
     c = M.Context(0)
     yield c
     c.close()

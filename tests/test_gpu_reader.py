@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
-    for k in ("MILZMA_KERNEL", "MILZMA_SPILL", "MILZMA_SLICE"):
-        os.environ.pop(k, None)
+    if os.environ.get("MILZMA_TEST_KEEP_ENV") != "1":   # (stress runs keep MILZMA_SLICE=2 / MILZMA_QUANTUM: every unit parked at every quantum)
+        for k in ("MILZMA_KERNEL", "MILZMA_SPILL", "MILZMA_SLICE"):
+            os.environ.pop(k, None)
     c = M.Context(0)
     yield c
     c.close()
