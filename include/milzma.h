@@ -180,7 +180,7 @@ int milzma_decode_units_wait(milzma_ctx *ctx, milzma_result *results);
  *                         a symbol only while MAX_REQUIRED_INPUT = 20 bytes are at hand or a trial run shows that fewer suffice).
  *                         Every unit's (in_off, in_len) is a VIEW: the bytes of its stream that are on the device so far.  A unit
  *                         decodes what is COMPLETE in its view -- like the reference: every symbol while 20 bytes are left, then
- *                         the symbols of the tail as far as they fit (units with lc + lp >= 4 leave the tail alone) -- and stops at
+ *                         the symbols of the tail as far as they fit -- and stops at
  *                         the symbol boundary in front of the first one that is not (an LZMA2 unit also: in front of a packet header
  *                         or a stored chunk that is not inside the view); fewer than 20 bytes are left unused then, and they belong
  *                         to that symbol or packet.  It is parked with (MILZMA_ST_NEED_INPUT, err_a = MILZMA_PARKED, in_consumed = bytes of THIS view it
@@ -432,9 +432,8 @@ uint32_t milzma_abi_version(void);
  * write (MILZMA_INFRA_ERROR: a HIP error, no memory) leaves the batch unusable: close it.
  * The crate decodes a symbol as soon as 20 bytes are at hand OR a trial run shows it complete within fewer (lzma.rs:455-516); so does
  * this implementation -- the tail of every write's data is decoded as far as its symbols are complete (a second pass over the tail
- * from a saved state, decode_fast_asm.hip.h) -- and a failed write is the very write the crate fails.  Two differences remain.  For
- * streams with lc + lp >= 4 (literal rows in device memory, which a saved state does not cover) the tail waits for the next write: an
- * error inside the last 19 bytes written so far is reported one call later (or by finish), never differently.  And nothing is decoded
+ * from a saved state; symbol by symbol, a state saved in front of each, for streams with lc + lp >= 4, whose literal rows live in device
+ * memory: decode_fast_asm.hip.h) -- and a failed write is the very write the crate fails.  One difference remains: nothing is decoded
  * BEHIND AN END MARKER: the crate's loop merely leaves at the marker, so
  * bytes written to the stream in a later call are decoded on from the marker's state (here: WriteZero), and a finish() that finds a
  * provided size not reached trips over the marker's distance ("Match distance 4294967296 is beyond dictionary size ..."; here: the
@@ -446,8 +445,8 @@ typedef struct milzma_streams milzma_streams;
  * not Stream::finish's "previous write error"; a header that never became complete as "header too short: ..." -- with in_consumed the
  * reader position of the whole stream.  A write that fails or reports WriteZero tells the caller to stop showing input and finish:
  * in_consumed minus the bytes of the pieces written BEFORE that one is how much of the last piece the reader is to consume
- * (integration/rust/src/lib.rs `run_fed`).  Exact for every stream whose literal rows are register resident (lc + lp <= 3); with
- * lc + lp >= 4 up to 19 bytes behind a stream's end may have been taken with an earlier piece. */
+ * (integration/rust/src/lib.rs `run_fed`): every byte a parked stream has not used belongs to a symbol that is not complete yet, so
+ * nothing behind a stream's end is ever taken with an earlier piece. */
 #define MILZMA_STREAMS_AS_READER 0x100u
 int milzma_streams_open(milzma_ctx *ctx, uint32_t kind, uint32_t n, const milzma_options *options, milzma_streams **out);
 int milzma_streams_write(milzma_streams *s, uint32_t k, const uint32_t *idx, const void *const *data, const size_t *len, int32_t *status);

@@ -8,10 +8,9 @@
 //   * State::Header (stream.rs:228-303): bytes are kept until the .lzma header and the range coder's five start bytes are there; a
 //     property byte >= 225 fails the write that delivers it;
 //   * State::Data (stream.rs:305-316, lzma.rs:435-524 in ProcessingMode::Partial): symbols are decoded while at least
-//     MAX_REQUIRED_INPUT = 20 bytes are at hand -- the kernel's FEED margin is that very number --; the reference also decodes a symbol
-//     that a TRIAL run shows to be complete within fewer bytes, the kernel leaves those for the next call.  Both stop in front of the
-//     same truncated symbol, so the difference shows only in WHEN an error inside the last 19 bytes of a call's data is reported (here:
-//     with the next call, or by finish) and in nothing a finished stream hands over;
+//     MAX_REQUIRED_INPUT = 20 bytes are at hand -- the kernel's FEED margin is that very number --, and with fewer as far as a TRIAL run
+//     shows them complete; the kernel does the same with a second pass over the tail of every view (decode_fast_asm.hip.h).  So a write
+//     fails in the very call the reference's fails in, and the bytes a stream has not used belong to a symbol that is not complete yet;
 //   * finish (stream.rs:119-150): the last view runs with MILZMA_KIND_LAST_VIEW; with allow_incomplete what stops in front of an
 //     incomplete symbol is a success with everything decoded so far.
 #include "host_internal.h"

@@ -4,8 +4,8 @@ restatement of src/decode/stream.rs (tests/test_oracle_stream.py pins that one t
 The reference's unit tests of the feature (src/decode/stream.rs:350-493) run here on the GPU path one to one; then random chunkings of
 streams of every kind -- good, truncated, damaged; every property class; known / unknown / provided sizes; memlimit -- many streams per
 batch, each on its own schedule (streams join late and sit calls out: MILZMA_KIND_START / _HOLD).  What must be EQUAL: what finish hands
-over (kind, message, bytes) and the text of a failed write.  What may differ (include/milzma.h): the call in which an error inside the last
-19 bytes written so far is reported -- the crate finds it by a trial run, this implementation with the next call or at finish."""
+over (kind, message, bytes), the text of a failed write, and the CALL that fails -- the tail of every write's data is decoded as far as its
+symbols are complete, the crate's trial-run rule (include/milzma.h)."""
 import os
 import random
 
@@ -92,28 +92,17 @@ def compare(comps, schedules, errs, decs, options=None, what="", skip=()):
         o_fail = [e for e in o_errs if e[1] != WRITE_ZERO]
         g_fail = [e for e in errs[i] if e[1] != WRITE_ZERO]
         d = decs[i]
-        # (streams with lc + lp >= 4 keep their literal rows in device memory: the tail of a write's data is not tried symbol by symbol
-        #  for them -- include/milzma.h --, so an error inside the last 19 bytes may be reported a call later than by the crate)
-        rows_in_hbm = len(comp) > 0 and comp[0] < 225 and (comp[0] % 9) + (comp[0] // 9) % 5 >= 4
         if not o_fail and not g_fail:
             assert (d.kind, d.msg) == (o_fin.kind, o_fin.msg), (what, i, d.msg, o_fin.msg)
             if o_fin.ok:
                 assert d.data == o_fin.out, (what, i, len(d.data), len(o_fin.out))
         elif o_fail and g_fail:
             assert g_fail[0][1] == o_fail[0][1], (what, i, g_fail[0], o_fail[0])
-            if rows_in_hbm:
-                assert g_fail[0][0] >= o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # never earlier than the crate
-                lagged += g_fail[0][0] > o_fail[0][0]
-            else:
-                assert g_fail[0][0] == o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # in the very call the crate reports it in
+            assert g_fail[0][0] == o_fail[0][0], (what, i, g_fail[0], o_fail[0])     # in the very call the crate reports it in
 
             assert (d.kind, d.msg) == (o_fin.kind, o_fin.msg) and "previous write error" in d.msg, (what, i, d.msg)
         elif o_fail:
-            # lc + lp >= 4 only: the crate reported it in a write, by a trial run on the last bytes; here it comes out of finish -- the same error
-            inner = o_fail[0][1]
-            assert rows_in_hbm, (what, i, "the crate's write fails, this one's does not", o_fail[0], d.msg)
-            assert inner.startswith('LzmaError("') and d.kind == M.LZMA_ERROR and d.msg == "lzma error: " + inner[len('LzmaError("'):-2], (what, i, d.msg, inner)
-            lagged += 1
+            raise AssertionError((what, i, "the crate's write fails, this one's does not", o_fail[0], d.msg))
         else:
             raise AssertionError((what, i, "a write failed that the crate's does not", g_fail[0]))
     return lagged
