@@ -313,7 +313,7 @@ fn run_fed<R: io::BufRead, W: io::Write>(
     let mut s = Streams { raw, n: 1 };
     let mut fed = first.len(); // bytes of the views consumed so far
     // (the one-shot call got through all of `first`: neither an end nor an error lies strictly inside it)
-    let mut more = s.write(&[(0, &first)])?.pop().expect("one piece").is_ok();
+    let mut more = s.write(&[(0, &first[..])])?.pop().expect("one piece").is_ok();
     while more {
         let view = input.fill_buf()?;
         if view.is_empty() {
