@@ -302,15 +302,7 @@ fn run_fed<R: io::BufRead, W: io::Write>(
     release(&mut out);
     // only its buffer's: from here on the views are fed, the first one (consumed already, kept in `first`) ahead of what the reader shows next
     let opts: Vec<decompress::Options> = options.map(|o| vec![*o]).unwrap_or_default();
-    let mut raw = ptr::null_mut();
-    let copts: Vec<ffi::milzma_options> = opts.iter().map(c_options).collect();
-    let rc = unsafe {
-        ffi::milzma_streams_open(ctx.raw, kind | ffi::MILZMA_STREAMS_AS_READER, 1, if copts.is_empty() { ptr::null() } else { copts.as_ptr() }, &mut raw)
-    };
-    if rc != ffi::MILZMA_OK {
-        return Err(infra("milzma_streams_open", unsafe { ffi::milzma_last_error(ctx.raw) }));
-    }
-    let mut s = Streams { raw, n: 1 };
+    let mut s = Streams::open(ctx, kind | ffi::MILZMA_STREAMS_AS_READER, 1, &opts)?;
     let mut fed = first.len(); // bytes of the views consumed so far
     // (the one-shot call got through all of `first`: neither an end nor an error lies strictly inside it)
     let mut more = s.write(&[(0, &first[..])])?.pop().expect("one piece").is_ok();
@@ -596,12 +588,23 @@ pub struct Streams {
 }
 
 impl Streams {
-    /// n x `Stream::new_with_options` (stream.rs:88-101); `options`: one per stream, or empty for `Options::default()`.
+    /// n x `Stream::new_with_options` (stream.rs:88-101) -- `.lzma` files, header first; `options`: one per stream, or empty for
+    /// `Options::default()`.
     pub fn new(ctx: &Context, n: usize, options: &[decompress::Options]) -> error::Result<Streams> {
+        Self::open(ctx, ffi::MILZMA_KIND_RAW_LZMA as u32, n, options)
+    }
+
+    /// n raw LZMA2 streams fed the same way (the crate has no such type; include/milzma.h).
+    pub fn new_lzma2(ctx: &Context, n: usize) -> error::Result<Streams> {
+        Self::open(ctx, ffi::MILZMA_KIND_LZMA2 as u32, n, &[])
+    }
+
+    /// `kind`: `MILZMA_KIND_RAW_LZMA` / `MILZMA_KIND_LZMA2`, optionally `| MILZMA_STREAMS_AS_READER` (finish = the one-shot verdict).
+    pub fn open(ctx: &Context, kind: u32, n: usize, options: &[decompress::Options]) -> error::Result<Streams> {
         assert!(options.is_empty() || options.len() == n);
         let copts: Vec<ffi::milzma_options> = options.iter().map(c_options).collect();
         let mut raw = ptr::null_mut();
-        let rc = unsafe { ffi::milzma_streams_open(ctx.raw, n as u32, if copts.is_empty() { ptr::null() } else { copts.as_ptr() }, &mut raw) };
+        let rc = unsafe { ffi::milzma_streams_open(ctx.raw, kind, n as u32, if copts.is_empty() { ptr::null() } else { copts.as_ptr() }, &mut raw) };
         if rc != ffi::MILZMA_OK {
             return Err(infra("milzma_streams_open", unsafe { ffi::milzma_last_error(ctx.raw) }));
         }
