@@ -442,8 +442,9 @@ typedef struct milzma_streams milzma_streams;
 /* or-ed into milzma_streams_open's `kind`: READER mode -- the streams stand for the crate's one-shot lzma_decompress / lzma2_decompress over
  * a `BufRead` that shows its input piece by piece (a BufReader over a socket or a large file): the pieces are written as they are shown,
  * and milzma_streams_finish hands over what the ONE-SHOT call would -- a failed decode's own error with the bytes written before it,
- * not Stream::finish's "previous write error"; a header that never became complete as "header too short: ..." -- with in_consumed the
- * reader position of the whole stream.  A write that fails or reports WriteZero tells the caller to stop showing input and finish:
+ * not Stream::finish's "previous write error"; a header that never became complete as "header too short: ..."; an end marker that
+ * ends one piece and is followed by another as "Found end-of-stream marker but more bytes are available" (the one-shot call asks the
+ * reader itself whether it is at its end) -- with in_consumed the reader position of the whole stream.  A write that fails or reports WriteZero tells the caller to stop showing input and finish:
  * in_consumed minus the bytes of the pieces written BEFORE that one is how much of the last piece the reader is to consume
  * (integration/rust/src/lib.rs `run_fed`): every byte a parked stream has not used belongs to a symbol that is not complete yet, so
  * nothing behind a stream's end is ever taken with an earlier piece. */
