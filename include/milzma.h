@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MILZMA_ABI_VERSION 5
+#define MILZMA_ABI_VERSION 6
 
 /* ---- error kinds: error::Error variants (src/error.rs:8-17) ---------------------------- */
 enum {
@@ -49,6 +49,13 @@ enum {
 #define MILZMA_KIND_HOLD 0x40u  /* ... in a RESUME | FEED call: this parked unit stays parked (nothing new for it); its result is kept */
 #define MILZMA_KIND_START 0x20u /* ... in a RESUME | FEED call: this unit is new -- it starts now, in the place i of the batch, beside the
                                    units that resume (continuous batching: the streams of a batch need not begin together) */
+
+#define MILZMA_KIND_PARTIAL 0x10u /* ... in a MILZMA_DECODE_FEED call, RAW units: the crate's ProcessingMode::Partial at an END MARKER
+                                     (src/decode/lzma.rs:493-495, :507-509): a marker that ends a view which is not the last (code == 0, no
+                                     byte of the view behind it) does not end the unit -- the crate's loop merely leaves, so bytes that
+                                     arrive later are decoded on from the marker's state (rep[0] = 0xFFFF_FFFF, the state after a match).
+                                     The unit parks behind the marker (MILZMA_ST_NEED_INPUT, in_consumed = the whole view) and resumes like
+                                     any fed unit; its LAST view ends it by the Finish-mode rules (lzma.rs:446-455, :513-521) */
 
 #define MILZMA_SIZE_UNKNOWN UINT64_MAX /* unpacked_size: Option::None => end-of-stream marker mode */
 #define MILZMA_NO_LIMIT UINT64_MAX     /* memlimit: Option::None                                    */
@@ -420,24 +427,43 @@ uint32_t milzma_abi_version(void);
  *                          ("LZMA header invalid properties: 255 must be < 225"), a decode error in the crate's Debug form
  *                          (`LzmaError("LZ distance 5 is beyond output size 3")`, stream.rs:343-347), or "failed to write whole buffer"
  *                          (ErrorKind::WriteZero: bytes behind a stream whose declared size is reached; the stream itself is intact,
- *                          tests/lzma.rs:71-87).  After a failed write (other than WriteZero) the stream takes further writes without
- *                          doing anything, as the reference does, and its finish() fails.  Returns MILZMA_INFRA_ERROR only for
- *                          infrastructure failures (milzma_streams_last_error).
+ *                          tests/lzma.rs:71-87).  After a failed write (other than WriteZero) the crate's Stream has no state left
+ *                          (stream.rs:230): write() returns Ok(0), so every later write_all of bytes is WriteZero too, and finish() fails.
+ *                          Returns MILZMA_INFRA_ERROR only for infrastructure failures (milzma_streams_last_error).
+ *                          An END MARKER that ends a write's data does NOT end a .lzma stream (the crate's Partial-mode loop merely leaves
+ *                          at ProcessingStatus::Finished, lzma.rs:493-495, :507-509): bytes written later are decoded on from the marker's
+ *                          state -- rep[0] = 0xFFFF_FFFF and code == 0, so the next decision says "literal", a matched one whose match
+ *                          byte lies 2^32 back: "Match distance 4294967296 is beyond dictionary size ..." from the write that brings the
+ *                          20th byte behind the marker (with fewer at hand the crate's trial run fails and it waits), or from finish --
+ *                          and a marker with bytes behind it in the same write is "Found end-of-stream marker but more bytes are available".
+ *   milzma_streams_write_taken  how many bytes of the most recent write stream i TOOK -- the sum of the Ok(n) the crate's Stream::write
+ *                          returns while write_all loops over it (stream.rs:324): all of them when the write succeeded; when it ended in
+ *                          WriteZero, the bytes in front of the stream's end (0 for a stream that had ended or failed before).  For a
+ *                          binding that implements io::Write::write, not only write_all.  "In front of the stream's end" is the crate's
+ *                          reckoning: once a write has ended inside a symbol, the crate decodes through its 20-byte partial-input buffer
+ *                          (lzma.rs:457-495), and when the stream then reaches its declared size the buffer has swallowed the 20 bytes
+ *                          from the last symbol's first byte on -- bytes behind the stream's end among them: they count as taken, and a
+ *                          write whose rest fits in there is NOT a WriteZero (the kernel notes where the last symbol began).
+ *   milzma_streams_output  Stream::get_output (stream.rs:102-116) for one stream: *sink_len = the bytes its sink holds right now -- every
+ *                          completed flush of the ring (whole multiples of the dictionary size, lzbuffer.rs:264-267; nothing before the
+ *                          header is complete) --, *has_sink = 0 after a failed write (the crate answers None), and the sink's bytes
+ *                          [offset, offset + cap) go to dst (a binding keeps the caller's `W` current by asking for what it has not
+ *                          delivered yet).  Before milzma_streams_finish only.
  *   milzma_streams_finish  Stream::finish (stream.rs:119-150) for every stream: outs[i] as from milzma_lzma_decompress -- kind / msg of
  *                          the crate's Result (header incomplete: "lzma error: failed to read header"; input ends early: "io error:
  *                          failed to fill whole buffer", unless allow_incomplete, which hands over everything decoded so far; after a
  *                          failed write: "lzma error: can't finish stream because of previous write error"), data = what the sink holds.
+ *                          A stream that stands behind an end marker gets the Finish-mode pass from that state (lzma.rs:446-455: done if no
+ *                          size is expected; a provided size not reached decodes on into the marker's distance).
  *                          Once; afterwards only milzma_streams_close (which may also be called without finish).
  * A milzma_streams is used by one thread at a time (like a context); different ones are independent.  An infrastructure failure of a
  * write (MILZMA_INFRA_ERROR: a HIP error, no memory) leaves the batch unusable: close it.
  * The crate decodes a symbol as soon as 20 bytes are at hand OR a trial run shows it complete within fewer (lzma.rs:455-516); so does
  * this implementation -- the tail of every write's data is decoded as far as its symbols are complete (a second pass over the tail
  * from a saved state; symbol by symbol, a state saved in front of each, for streams with lc + lp >= 4, whose literal rows live in device
- * memory: decode_fast_asm.hip.h) -- and a failed write is the very write the crate fails.  One difference remains: nothing is decoded
- * BEHIND AN END MARKER: the crate's loop merely leaves at the marker, so
- * bytes written to the stream in a later call are decoded on from the marker's state (here: WriteZero), and a finish() that finds a
- * provided size not reached trips over the marker's distance ("Match distance 4294967296 is beyond dictionary size ..."; here: the
- * one-shot call's "Expected unpacked size of {} but decompressed to {}"). */
+ * memory: decode_fast_asm.hip.h) -- and a failed write is the very write the crate fails.
+ * A .lzma stream whose header asks for more literal rows (lc + lp) than the batch's slab keeps per stream -- 8 for large batches, every
+ * legal value for small ones -- is decoded in a one-stream batch of its own behind the same calls: it costs the other streams nothing. */
 typedef struct milzma_streams milzma_streams;
 /* or-ed into milzma_streams_open's `kind`: READER mode -- the streams stand for the crate's one-shot lzma_decompress / lzma2_decompress over
  * a `BufRead` that shows its input piece by piece (a BufReader over a socket or a large file): the pieces are written as they are shown,
@@ -455,6 +481,9 @@ const char *milzma_streams_write_error(const milzma_streams *s, uint32_t stream)
 int milzma_streams_finish(milzma_streams *s, milzma_output *outs);
 void milzma_streams_close(milzma_streams *s);
 const char *milzma_streams_last_error(const milzma_streams *s);
+uint64_t milzma_streams_write_taken(const milzma_streams *s, uint32_t stream);
+int milzma_streams_output(milzma_streams *s, uint32_t stream, uint64_t offset, void *dst, size_t cap, uint64_t *sink_len,
+                          int32_t *has_sink);
 
 #ifdef __cplusplus
 }

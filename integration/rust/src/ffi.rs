@@ -4,7 +4,7 @@
 
 use std::os::raw::{c_char, c_float, c_int, c_void};
 
-pub const MILZMA_ABI_VERSION: u32 = 5;
+pub const MILZMA_ABI_VERSION: u32 = 6;
 
 // error kinds: error::Error variants (src/error.rs:8-17)
 pub const MILZMA_OK: c_int = 0;
@@ -22,6 +22,8 @@ pub const MILZMA_KIND_LAST_VIEW: u8 = 0x80;
 pub const MILZMA_KIND_HOLD: u8 = 0x40;
 /// ... in a RESUME | FEED call: this unit is new and starts now, beside the units that resume
 pub const MILZMA_KIND_START: u8 = 0x20;
+/// ... in a FEED call, RAW units: an end marker that ends a view which is not the last does not end the unit (the crate's Partial mode)
+pub const MILZMA_KIND_PARTIAL: u8 = 0x10;
 pub const MILZMA_SIZE_UNKNOWN: u64 = u64::MAX;
 pub const MILZMA_NO_LIMIT: u64 = u64::MAX;
 pub const MILZMA_MAX_UNIT_BYTES: u64 = 0xFFFF_FF00;
@@ -337,4 +339,14 @@ extern "C" {
     pub fn milzma_streams_finish(s: *mut milzma_streams, outs: *mut milzma_output) -> c_int;
     pub fn milzma_streams_close(s: *mut milzma_streams);
     pub fn milzma_streams_last_error(s: *const milzma_streams) -> *const c_char;
+    pub fn milzma_streams_write_taken(s: *const milzma_streams, stream: u32) -> u64;
+    pub fn milzma_streams_output(
+        s: *mut milzma_streams,
+        stream: u32,
+        offset: u64,
+        dst: *mut c_void,
+        cap: usize,
+        sink_len: *mut u64,
+        has_sink: *mut i32,
+    ) -> c_int;
 }

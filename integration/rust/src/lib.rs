@@ -276,8 +276,12 @@ fn run<R: io::BufRead, W: io::Write>(
 
 /// `run` for the two entry points whose decoder can be FED (`.lzma`, LZMA2; round 5): if the first view is not the whole input, the
 /// views are written to a push-mode stream in READER mode as `fill_buf` shows them (`MILZMA_STREAMS_AS_READER`, include/milzma.h) --
-/// nothing is read twice, nothing is decoded twice, and the reader is left exactly where the reference's would stand: right behind a
-/// stream of known size or an LZMA2 end byte, at the failing byte of a damaged one.  (`tests/test_gpu_reader.py` runs this loop --
+/// nothing is read twice, and the reader is left exactly where the reference's would stand: right behind a stream of known size or an
+/// LZMA2 end byte, at the failing byte of a damaged one.  What it costs: the FIRST view is decoded twice (by the one-shot call that
+/// finds out whether the reader shows everything at once, then as the stream's first piece), and every later view is one upload, one
+/// launch and one wait of its own on a batch of ONE stream -- with `BufReader`'s default 8 KiB that is 130 000 serial launches per GiB.
+/// Give the reader a large buffer (`BufReader::with_capacity(64 << 20, file)`: a view per 64 MiB), or, for many files, read them and use
+/// the `*_batch` calls: a single stream never fills the chip either way.  (`tests/test_gpu_reader.py` runs this loop --
 /// `lzma_rs_amd.decompress_reader` -- for buffers of 1 byte to everything against the oracle.)
 fn run_fed<R: io::BufRead, W: io::Write>(
     ctx: &Context,
@@ -580,8 +584,8 @@ pub fn xz_decompress_batches_pipelined<'f>(
 /// `lzma_rs::decompress::Stream` (feature `stream`, src/decode/stream.rs) for a BATCH of streams on one GPU: the compressed `.lzma`
 /// bytes of each stream are written piece by piece, `finish` hands every stream's verdict and output over.  One `write` call gives any
 /// number of the streams another turn in ONE launch (fed input, `MILZMA_DECODE_FEED`: streams start when their header is complete,
-/// resume where they parked, or sit the call out).  Where this differs from the crate -- WHEN an error inside the last 19 bytes written
-/// so far is reported, and that nothing is decoded behind an end marker -- is spelled out in include/milzma.h.
+/// resume where they parked, or sit the call out).  Verdicts, texts, bytes and the call that fails are the crate's, behind an end marker too
+/// (include/milzma.h).
 pub struct Streams {
     raw: *mut ffi::milzma_streams,
     n: usize,
@@ -652,54 +656,119 @@ impl Drop for Streams {
     }
 }
 
-/// ONE push-mode decoder with the crate's own shape -- `Stream::new(output)`, `io::Write`, `finish() -> Result<W>` -- for code that is
-/// written against `lzma_rs::decompress::Stream<W>`.  (A batch of one stream leaves the GPU idle: `Streams` is the form to use when many
-/// streams arrive at once.)  The output reaches `W` at `finish`; `get_output` shows the sink as it is.
+/// ONE push-mode decoder with the crate's own shape -- `Stream::new(output) -> Self`, `io::Write`, `get_output`, `finish() -> Result<W>`
+/// (src/decode/stream.rs:80-151) -- for code that is written against `lzma_rs::decompress::Stream<W>`.  (A batch of one stream leaves the
+/// GPU idle: `Streams` is the form to use when many streams arrive at once.)
+///
+/// The sink is kept as the crate keeps it: every `write` hands `W` what the ring has flushed since (whole multiples of the dictionary
+/// size, lzbuffer.rs:264-267), `finish` the rest; after a failed write the crate has dropped its state and the sink with it
+/// (stream.rs:230) -- `get_output` answers `None` from then on here too.
 pub struct Stream<W: io::Write> {
+    /// `None`: the batch behind this stream could not be opened (no GPU, no memory).  `new` cannot fail in the crate, so the first `write`
+    /// / `finish` reports it (`open_error`).
     inner: Option<Streams>,
+    open_error: Option<String>,
     output: Option<W>,
+    /// bytes of the sink that `output` has got already
+    delivered: u64,
 }
 
 impl<W: io::Write> Stream<W> {
-    pub fn new(output: W) -> error::Result<Self> {
+    /// `Stream::new` (stream.rs:86-88)
+    pub fn new(output: W) -> Self {
         Self::new_with_options(&decompress::Options::default(), output)
     }
 
-    pub fn new_with_options(options: &decompress::Options, output: W) -> error::Result<Self> {
-        let inner = with_default_ctx(|ctx| Streams::new(ctx, 1, std::slice::from_ref(options)))?;
-        Ok(Stream { inner: Some(inner), output: Some(output) })
+    /// `Stream::new_with_options` (stream.rs:93-99)
+    pub fn new_with_options(options: &decompress::Options, output: W) -> Self {
+        match with_default_ctx(|ctx| Streams::new(ctx, 1, std::slice::from_ref(options))) {
+            Ok(inner) => Stream { inner: Some(inner), open_error: None, output: Some(output), delivered: 0 },
+            Err(e) => Stream { inner: None, open_error: Some(e.to_string()), output: Some(output), delivered: 0 },
+        }
     }
 
+    /// `Stream::get_output` (stream.rs:102-107): the sink, holding everything the ring has flushed so far; `None` after a failed write.
     pub fn get_output(&self) -> Option<&W> {
         self.output.as_ref()
     }
 
+    /// `Stream::get_output_mut` (stream.rs:110-115)
     pub fn get_output_mut(&mut self) -> Option<&mut W> {
         self.output.as_mut()
     }
 
+    /// What the ring has flushed since the last call goes to `W` (`milzma_streams_output`); a stream whose state is gone drops `W`.
+    fn sync_sink(&mut self) -> io::Result<()> {
+        let inner = match self.inner.as_ref() {
+            Some(s) => s,
+            None => return Ok(()),
+        };
+        let (mut len, mut has) = (0u64, 0i32);
+        let rc = unsafe { ffi::milzma_streams_output(inner.raw, 0, 0, ptr::null_mut(), 0, &mut len, &mut has) };
+        if rc != ffi::MILZMA_OK {
+            return Err(io::Error::new(io::ErrorKind::Other, infra("milzma_streams_output", unsafe { ffi::milzma_streams_last_error(inner.raw) }).to_string()));
+        }
+        if has == 0 {
+            self.output = None;
+            return Ok(());
+        }
+        if len > self.delivered {
+            let mut buf = vec![0u8; (len - self.delivered) as usize];
+            let rc = unsafe { ffi::milzma_streams_output(inner.raw, 0, self.delivered, buf.as_mut_ptr() as *mut _, buf.len(), &mut len, &mut has) };
+            if rc != ffi::MILZMA_OK {
+                return Err(io::Error::new(io::ErrorKind::Other, infra("milzma_streams_output", unsafe { ffi::milzma_streams_last_error(inner.raw) }).to_string()));
+            }
+            if let Some(w) = self.output.as_mut() {
+                w.write_all(&buf)?;
+            }
+            self.delivered += buf.len() as u64;
+        }
+        Ok(())
+    }
+
     /// Stream::finish (stream.rs:119-150): the sink with everything decoded, or the stream's error.
     pub fn finish(mut self) -> error::Result<W> {
-        let inner = self.inner.take().expect("finish is called once");
-        let mut output = self.output.take().expect("finish is called once");
+        let inner = match self.inner.take() {
+            Some(s) => s,
+            None => return Err(error::Error::IoError(io::Error::new(io::ErrorKind::Other, self.open_error.take().unwrap_or_default()))),
+        };
         let mut done = inner.finish();
         let d = done.pop().expect("one stream");
         d.result?;
-        output.write_all(&d.data)?;
+        // (Ok: the state was there, and so is the sink)
+        let mut output = self.output.take().expect("a stream that finishes well has its sink");
+        output.write_all(&d.data[(self.delivered as usize).min(d.data.len())..])?;
         output.flush()?;
         Ok(output)
     }
 }
 
 impl<W: io::Write> io::Write for Stream<W> {
+    /// `Stream::write` (stream.rs:227-325): `Ok(n)`, the bytes the stream took -- all of them, or, where the stream ends inside `data`
+    /// (its declared size is reached), the ones in front of its end; `Ok(0)` from a stream that has ended or whose state is gone, which
+    /// `write_all` turns into `ErrorKind::WriteZero` as it does for the crate.
     fn write(&mut self, data: &[u8]) -> io::Result<usize> {
-        let inner = self.inner.as_mut().expect("not finished");
+        if data.is_empty() {
+            return Ok(0);
+        }
+        let inner = match self.inner.as_mut() {
+            Some(s) => s,
+            None => return Err(io::Error::new(io::ErrorKind::Other, self.open_error.clone().unwrap_or_default())),
+        };
         let mut r = inner
             .write(&[(0, data)])
             .map_err(|e| io::Error::new(io::ErrorKind::Other, e.to_string()))?;
-        r.pop().expect("one piece").map(|_| data.len())
+        let taken = unsafe { ffi::milzma_streams_write_taken(inner.raw, 0) } as usize;
+        let verdict = r.pop().expect("one piece");
+        self.sync_sink()?;
+        match verdict {
+            Ok(()) => Ok(data.len()),
+            Err(e) if e.kind() == io::ErrorKind::WriteZero => Ok(taken.min(data.len())),
+            Err(e) => Err(e),
+        }
     }
 
+    /// `Stream::flush` (stream.rs:330-339): the sink's own flush (the ring is not flushed: that would corrupt the state)
     fn flush(&mut self) -> io::Result<()> {
         match self.output.as_mut() {
             Some(w) => w.flush(),

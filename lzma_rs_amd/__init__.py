@@ -39,6 +39,7 @@ DECODE_GROW, DECODE_RESUME, DECODE_FEED = 1, 2, 4   # flags of decode_units_ex (
 ST_NEED_INPUT = 37              # ... DECODE_FEED: parked within 20 bytes of the end of its input view (err_a == PARKED)
 STREAMS_AS_READER = 0x100       # or-ed into Streams' kind: finish() = the verdict of the one-shot call over a reader (MILZMA_STREAMS_AS_READER)
 KIND_LAST_VIEW = 0x80           # or-ed into Unit.kind in a DECODE_FEED call: the view ends where the stream ends
+KIND_PARTIAL = 0x10             # ... an end marker that ends a view which is not the last does not end the unit (the crate's Partial mode)
 
 
 class Error(Exception):
@@ -154,7 +155,7 @@ EXPORTS = [
     "milzma_decode_units_ex", "milzma_move_units", "milzma_pool_trim",
     "milzma_multi_decode_units_rooted", "milzma_multi_last_transfer_ms",
     "milzma_streams_open", "milzma_streams_write", "milzma_streams_write_error", "milzma_streams_finish", "milzma_streams_close",
-    "milzma_streams_last_error",
+    "milzma_streams_last_error", "milzma_streams_output", "milzma_streams_write_taken",
 ]
 
 _lib = None
@@ -247,6 +248,10 @@ def lib():
     L.milzma_streams_close.argtypes = [vp]
     L.milzma_streams_last_error.restype = ctypes.c_char_p
     L.milzma_streams_last_error.argtypes = [vp]
+    L.milzma_streams_write_taken.restype = ctypes.c_uint64
+    L.milzma_streams_write_taken.argtypes = [vp, ctypes.c_uint32]
+    L.milzma_streams_output.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.POINTER(ctypes.c_int32)]
     _lib = L
     return L
 
@@ -613,6 +618,23 @@ class Streams:
         if lib().milzma_streams_write(self._h, k, idx, ptrs, lens, status) != OK:
             raise InfraError("milzma_streams_write: " + lib().milzma_streams_last_error(self._h).decode())
         return {items[j][0]: lib().milzma_streams_write_error(self._h, items[j][0]).decode() for j in range(k) if status[j] != OK}
+
+    def taken(self, i):
+        """bytes of the most recent write that stream i took (the sum of the Ok(n) of the crate's Stream::write under write_all)"""
+        return lib().milzma_streams_write_taken(self._h, i)
+
+    def output(self, i):
+        """Stream::get_output (stream.rs:102-116) of stream i: the bytes its sink holds right now (every completed flush of the ring), or
+        None after a failed write (the crate's state is gone)."""
+        n, has = ctypes.c_uint64(), ctypes.c_int32()
+        if lib().milzma_streams_output(self._h, i, 0, None, 0, ctypes.byref(n), ctypes.byref(has)) != OK:
+            raise InfraError("milzma_streams_output: " + lib().milzma_streams_last_error(self._h).decode())
+        if not has.value:
+            return None
+        buf = ctypes.create_string_buffer(max(1, n.value))
+        if n.value and lib().milzma_streams_output(self._h, i, 0, buf, n.value, ctypes.byref(n), ctypes.byref(has)) != OK:
+            raise InfraError("milzma_streams_output: " + lib().milzma_streams_last_error(self._h).decode())
+        return buf.raw[:n.value]
 
     def finish(self):
         outs = (_COutput * self.n)()

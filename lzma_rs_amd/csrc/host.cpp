@@ -667,8 +667,8 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
   // the same floor (the kernels divide by dict_size).
   ctx->pend_units.assign(units, units + n);
   for (milzma_unit& u : ctx->pend_units)
-    if ((u.kind & (feed ? 0x1Fu : 0xFFu)) == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
-  // (fed input: MILZMA_KIND_LAST_VIEW is for the kernel; everything on the host side looks at the plain kind)
+    if ((u.kind & (feed ? 0x0Fu : 0xFFu)) == MILZMA_KIND_RAW_LZMA && u.dict_size < 0x1000u) u.dict_size = 0x1000u;
+  // (fed input: MILZMA_KIND_LAST_VIEW and MILZMA_KIND_PARTIAL are for the kernel; everything on the host side looks at the plain kind)
   ctx->feed_units.clear();
   std::vector<uint8_t> marks;   // MILZMA_KIND_START / _HOLD of each unit (host side only: the device sees the kind and LAST_VIEW)
   if (feed) {
@@ -678,7 +678,7 @@ int milzma_decode_units_async_impl(milzma_ctx* ctx, const milzma_unit* units, ui
       ctx->pend_units[i].kind &= uint8_t(~(MILZMA_KIND_START | MILZMA_KIND_HOLD));
     }
     ctx->feed_units = ctx->pend_units;
-    for (milzma_unit& u : ctx->pend_units) u.kind &= uint8_t(~MILZMA_KIND_LAST_VIEW);
+    for (milzma_unit& u : ctx->pend_units) u.kind &= uint8_t(~(MILZMA_KIND_LAST_VIEW | MILZMA_KIND_PARTIAL));
   }
   const milzma_unit* const units_up = feed ? ctx->feed_units.data() : ctx->pend_units.data();
   units = ctx->pend_units.data();

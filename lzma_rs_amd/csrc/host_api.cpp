@@ -376,6 +376,9 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
 MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S);
 MILZMA_HIDDEN const char* milzma_streams_write_error_impl(const milzma_streams* S, uint32_t stream);
 MILZMA_HIDDEN const char* milzma_streams_last_error_impl(const milzma_streams* S);
+MILZMA_HIDDEN uint64_t milzma_streams_write_taken_impl(const milzma_streams* S, uint32_t stream);
+MILZMA_HIDDEN int milzma_streams_output_impl(milzma_streams* S, uint32_t stream, uint64_t offset, void* dst, size_t cap, uint64_t* sink_len,
+                                            int32_t* has_sink);
 
 extern "C" int milzma_streams_open(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out) {
   begin_call(ctx);
@@ -408,3 +411,12 @@ extern "C" int milzma_streams_finish(milzma_streams* s, milzma_output* outs) {
 extern "C" void milzma_streams_close(milzma_streams* s) { milzma_streams_close_impl(s); }
 extern "C" const char* milzma_streams_write_error(const milzma_streams* s, uint32_t stream) { return milzma_streams_write_error_impl(s, stream); }
 extern "C" const char* milzma_streams_last_error(const milzma_streams* s) { return milzma_streams_last_error_impl(s); }
+
+extern "C" int milzma_streams_output(milzma_streams* s, uint32_t stream, uint64_t offset, void* dst, size_t cap, uint64_t* sink_len, int32_t* has_sink) {
+  try {
+    return milzma_streams_output_impl(s, stream, offset, dst, cap, sink_len, has_sink);
+  } catch (const std::exception&) {
+    return MILZMA_INFRA_ERROR;
+  }
+}
+extern "C" uint64_t milzma_streams_write_taken(const milzma_streams* s, uint32_t stream) { return milzma_streams_write_taken_impl(s, stream); }

@@ -11,8 +11,13 @@
 //     MAX_REQUIRED_INPUT = 20 bytes are at hand -- the kernel's FEED margin is that very number --, and with fewer as far as a TRIAL run
 //     shows them complete; the kernel does the same with a second pass over the tail of every view (decode_fast_asm.hip.h).  So a write
 //     fails in the very call the reference's fails in, and the bytes a stream has not used belong to a symbol that is not complete yet;
+//   * an END MARKER that ends a write's data (lzma.rs:493-495, :507-509): Partial mode merely leaves its loop at `Finished`; the stream
+//     stays in State::Data with the marker's state, and bytes written later are decoded on from it.  The units of .lzma streams carry
+//     MILZMA_KIND_PARTIAL: they park behind such a marker like a unit that needs input (decode_fast_asm.hip.h), so a later write -- good
+//     bytes, garbage, another stream -- gets the crate's verdict, and finish() its Finish-mode pass from that state;
 //   * finish (stream.rs:119-150): the last view runs with MILZMA_KIND_LAST_VIEW; with allow_incomplete what stops in front of an
-//     incomplete symbol is a success with everything decoded so far.
+//     incomplete symbol is a success with everything decoded so far;
+//   * get_output (stream.rs:102-116): the sink holds every completed flush of the ring (lzbuffer.rs:264-267): milzma_streams_output.
 #include "host_internal.h"
 
 using namespace milzma;
@@ -21,13 +26,20 @@ using namespace milzma::host;
 namespace {
 
 struct One {
-  enum St : uint8_t { HEADER, DATA, DONE, FAILED } st = HEADER;
+  // SIDE: a .lzma stream with more literal rows (lc + lp) than the batch's slab has per stream lives in a one-stream batch of its own
+  // (`side`: a context and a slab for itself); every call on it is passed on
+  enum St : uint8_t { HEADER, DATA, DONE, FAILED, SIDE } st = HEADER;
+  milzma_streams* side = nullptr;
   milzma_options opt;
   std::vector<uint8_t> pending;   // HEADER: the header bytes so far; DATA: payload that has arrived and is not consumed yet
   size_t hdr_len = 0;
   uint64_t consumed = 0;           // payload bytes the decoder has taken
   bool started = false;            // its unit has been launched (it owns an output slice)
   std::string write_err;           // text of the io::Error of the write that failed
+  uint64_t taken = 0;              // bytes of the last write the stream took (what Stream::write's Ok(n) add up to, stream.rs:324)
+  size_t in_tmp = 0;               // bytes (pending[5 .. 5 + in_tmp)) that the crate holds in Stream.tmp behind a header it read through that
+                                   // buffer: its next write() call's first input (stream.rs:312-317); the unit has not started yet
+  size_t view = 0;                 // feed_round: only this much of `pending` is the unit's view (0: all of it)
   // reader mode (MILZMA_STREAMS_AS_READER): what the failed decode itself said, for finish to hand over instead of Stream::finish's
   // "previous write error"
   bool has_fail = false;
@@ -57,7 +69,16 @@ struct milzma_streams {
   bool finished = false;
   uint32_t kind = MILZMA_KIND_RAW_LZMA;   // MILZMA_KIND_RAW_LZMA: .lzma files (header first, as the crate's Stream); MILZMA_KIND_LZMA2: raw LZMA2 streams
   bool as_reader = false;      // finish hands over what the ONE-SHOT call would (lzma_decompress over a reader that shows its input piece by piece)
+  // the crate's Partial mode at an end marker (MILZMA_KIND_PARTIAL): .lzma streams in Stream mode.  (Reader mode stands for the one-shot
+  // call, whose range decoder asks the READER whether it is at its end; LZMA2 streams end at their end byte.)
+  bool partial() const { return kind == MILZMA_KIND_RAW_LZMA && !as_reader; }
 };
+
+MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out);
+MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len,
+                                           int32_t* status);
+MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* outs);
+MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S);
 
 MILZMA_HOST_NS_BEGIN
 
@@ -136,40 +157,44 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
     size_t in_total = 0;
     for (uint32_t i : active) {
       is_active[i] = 1;
+      const size_t view = S->s[i].view ? std::min(S->s[i].view, S->s[i].pending.size()) : S->s[i].pending.size();
       S->units[i].in_off = in_total;
-      S->units[i].in_len = S->s[i].pending.size();
-      in_total += round_up(S->s[i].pending.size(), 64) + 64;
+      S->units[i].in_len = view;
+      in_total += round_up(view, 64) + 64;
     }
     if (!pin_reserve(ctx, ctx->pin_in, in_total + 512) || !dev_reserve(ctx, ctx->in, in_total + 512)) return false;
     parallel_for(active.size(), [&](size_t a) {
       const uint32_t i = active[a];
-      if (!S->s[i].pending.empty()) memcpy(static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off, S->s[i].pending.data(), S->s[i].pending.size());
+      if (S->units[i].in_len) memcpy(static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off, S->s[i].pending.data(), size_t(S->units[i].in_len));
     });
     if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
         !hip_ok(ctx, hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_total, hipMemcpyHostToDevice, work_stream(ctx)), "H2D views"))
       return false;
     for (uint32_t i = 0; i < S->n; i++) {
-      uint8_t k = S->units[i].kind & (MILZMA_KIND_START | 0x1Fu);
+      uint8_t k = S->units[i].kind & (MILZMA_KIND_START | 0x0Fu);
       if (!is_active[i]) {
         k &= uint8_t(~MILZMA_KIND_START);
         if (parked(S->res[i])) k |= MILZMA_KIND_HOLD;
       } else if (last) {
         k |= MILZMA_KIND_LAST_VIEW;
+      } else if (S->partial()) {
+        k |= MILZMA_KIND_PARTIAL;
       }
       S->units[i].kind = k;
     }
     const int rc = milzma_decode_units_impl(ctx, S->units.data(), S->n, ctx->in.p, S->out.p, S->res.data(), work_stream(ctx),
                                             MILZMA_DECODE_RESUME | MILZMA_DECODE_FEED);
-    for (uint32_t i = 0; i < S->n; i++) S->units[i].kind &= 0x1Fu;
+    for (uint32_t i = 0; i < S->n; i++) S->units[i].kind &= 0x0Fu;
     if (rc != MILZMA_OK) return false;
     std::vector<uint32_t> again;
     std::vector<std::pair<uint32_t, uint64_t>> want;
     for (uint32_t i : active) {
       One& o = S->s[i];
       const milzma_result& r = S->res[i];
-      const uint64_t took = std::min<uint64_t>(r.in_consumed, o.pending.size());
+      const uint64_t took = std::min<uint64_t>(r.in_consumed, S->units[i].in_len);
       o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(took));
       o.consumed += took;
+      if (o.view) o.view -= size_t(took);   // (0 only with everything taken: nothing of the view is left for another round)
       if (parked(r) && r.status == MILZMA_ST_OUT_FULL) {   // more room: what its progress predicts for the bytes at hand, at least 2.5 x
         const long double rate = (long double)(r.out_len + 1) / (long double)std::max<uint64_t>(1, o.consumed);
         uint64_t cap = uint64_t(rate * (long double)(o.consumed + o.pending.size()) * 1.25L) + 65536;
@@ -221,14 +246,103 @@ MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint3
     memset(&S->units[i], 0, sizeof(milzma_unit));
     memset(&S->res[i], 0, sizeof(milzma_result));
   }
-  // literal rows for streams that join later: as many per stream as a quarter of the free memory allows (lc + lp up to 8 by default)
+  // Literal rows for streams that join later: the batch's slab has ONE stride, fixed by its first launch of the class -- as many rows per
+  // stream as a quarter of the free memory allows: every legal lc + lp (12: 6 MiB per stream) for a small batch (256 MiB in all), 8 (384
+  // KiB per stream) otherwise.  A .lzma stream that asks for more gets a one-stream batch of its own (One::SIDE), so its header byte
+  // costs nobody else anything.
   size_t free_b = 0, total_b = 0;
-  uint32_t lclp = 8;
+  uint32_t lclp = 12;
+  while (lclp > 8 && (size_t(1536) << lclp) * std::max<uint32_t>(n, 1) > (size_t(256) << 20)) lclp--;
   if (hipSetDevice(own->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
     while (lclp > 4 && (size_t(1536) << lclp) * std::max<uint32_t>(n, 1) > free_b / 4) lclp--;
   own->slab_min_lclp = lclp;
   *out = S;
   return MILZMA_OK;
+}
+
+// A stream of its own for stream i (One::SIDE): everything written so far goes there first.  status / write_err as from a write.
+static bool to_side(milzma_streams* S, uint32_t i, size_t before, int32_t* st) {
+  One& o = S->s[i];
+  milzma_streams* side = nullptr;
+  if (milzma_streams_open_impl(S->ctx, S->kind | (S->as_reader ? MILZMA_STREAMS_AS_READER : 0u), 1, &o.opt, &side) != MILZMA_OK) return false;
+  const uint32_t zero = 0;
+  const void* data = o.pending.data();
+  const size_t len = o.pending.size();
+  int32_t s1 = MILZMA_OK;
+  if (milzma_streams_write_impl(side, 1, &zero, &data, &len, &s1) != MILZMA_OK) {
+    S->ctx->err = side->ctx->err;
+    milzma_streams_close_impl(side);
+    return false;
+  }
+  o.side = side;
+  o.st = One::SIDE;
+  o.pending.clear();
+  o.pending.shrink_to_fit();
+  o.write_err = side->s[0].write_err;
+  o.taken = side->s[0].taken > before ? side->s[0].taken - before : 0;   // (of THIS write's bytes: `before` were buffered by earlier writes)
+  *st = s1;
+  return true;
+}
+
+// One CURSOR of a write: the bytes one call of the crate's Stream::write hands to process_stream as its `input` (stream.rs:305-319) -- the
+// written data, or, in front of it, what a header read through Stream.tmp had left in that buffer (stream.rs:312-317: a call of its
+// own).  The unit's view is what it holds un-decoded (the bytes of an incomplete symbol: the crate's partial-input buffer; for a unit that
+// starts, the range coder's five start bytes) + the cursor's `data` bytes; `view` > 0: only that much of what is pending (the rest
+// belongs to the next cursor).
+struct WriteCursor {
+  uint32_t j, i;
+  size_t data, view;
+};
+
+// The cursors in `cur` take their turn (one feed_round), then every stream's verdict: its state, st[j] / write_err, and refused[j] = how
+// many of the cursor's bytes the crate's write() would NOT have taken (> 0: write_all's ErrorKind::WriteZero).  A stream that reaches its
+// declared size takes nothing more -- but what the crate had moved into its partial-input buffer by then is taken (lzma.rs:420-433,
+// :457-495): on that path (entered where a cursor ends inside a symbol, so: whenever a cursor begins with such bytes at hand) every
+// iteration first fills the buffer to 20 bytes, counted from the symbol's first byte; off it, the reader stands at the stream's last byte.
+static bool run_cursors(milzma_streams* S, const std::vector<WriteCursor>& cur, std::vector<int32_t>& st, std::vector<uint64_t>* refused) {
+  if (cur.empty()) return true;
+  std::vector<uint32_t> active;
+  std::vector<size_t> total(cur.size()), begin(cur.size()), behind(cur.size());
+  std::vector<uint8_t> partial_path(cur.size());
+  for (size_t c = 0; c < cur.size(); c++) {
+    One& o = S->s[cur[c].i];
+    total[c] = cur[c].view ? std::min(cur[c].view, o.pending.size()) : o.pending.size();
+    behind[c] = o.pending.size() - total[c];
+    begin[c] = total[c] - std::min(cur[c].data, total[c]);
+    partial_path[c] = S->partial() && o.started && begin[c] > 0;   // (a unit that starts holds the five start bytes, not a symbol's)
+    o.view = cur[c].view;
+    active.push_back(cur[c].i);
+  }
+  const bool ok = feed_round(S, active, false);
+  for (const WriteCursor& c : cur) S->s[c.i].view = 0;
+  if (!ok) return false;
+  for (size_t c = 0; c < cur.size(); c++) {
+    const uint32_t i = cur[c].i, j = cur[c].j;
+    One& o = S->s[i];
+    const milzma_result& r = S->res[i];
+    if (parked(r)) continue;   // wants more input (or stands behind an end marker, MILZMA_KIND_PARTIAL): everything was taken
+    if (r.status == MILZMA_ST_OK || r.status == MILZMA_ST_SIZE_MISMATCH) {
+      // the stream has ended (its declared size is reached -- exactly, or overshot by its last match; reader mode / LZMA2: its end marker
+      // / end byte has been read with nothing behind it): Partial mode leaves its loop; "Expected unpacked size ..." is a check of
+      // finish() (lzma.rs:513-521, Finish mode only)
+      o.st = One::DONE;
+      const size_t left = o.pending.size() - std::min(behind[c], o.pending.size());   // bytes of the view the decoder has not used
+      const size_t end = total[c] - std::min(left, total[c]);                          // the reader's position in the view
+      size_t slurped = end;
+      if (partial_path[c]) {
+        const size_t top = end - std::min<size_t>(end, r.chunks);   // where the last symbol began (the kernel notes it: decode_fast_asm.hip.h, near_step)
+        slurped = std::min<size_t>(top + 20, total[c]);
+      }
+      if (refused) (*refused)[j] += total[c] - std::min(total[c], std::max(slurped, begin[c]));
+    } else {
+      o.write_err = debug_lzma_error(r, S->kind);
+      o.fail = r;
+      o.has_fail = true;
+      o.st = One::FAILED;
+      st[j] = MILZMA_IO_ERROR;
+    }
+  }
+  return true;
 }
 
 MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const uint32_t* idx, const void* const* data, const size_t* len,
@@ -252,13 +366,16 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
     }
     seen[idx[j]] = 1;
   }
-  std::vector<uint32_t> active;
   std::vector<int32_t> st(k, MILZMA_OK);
+  std::vector<uint64_t> refused(k, 0);   // bytes of the write the stream does not take (> 0: ErrorKind::WriteZero)
+  std::vector<size_t> before(k, 0);      // bytes the stream held when the call began
+  bool side_failed = false;              // an infrastructure failure of a stream that lives in a batch of its own
   // the bytes first, every stream's on its own (streams in Header / Data state keep them), on the host threads
   std::atomic<int> no_memory{0};
   parallel_for(k, [&](size_t j) {
     One& o = S->s[idx[j]];
-    if (len[j] && (o.st == One::HEADER || o.st == One::DATA)) {
+    before[j] = o.pending.size();
+    if (len[j] && (o.st == One::HEADER || o.st == One::DATA)) {   // (a SIDE stream's bytes are passed on below)
       const uint8_t* p = static_cast<const uint8_t*>(data[j]);
       try {   // (an exception must not leave a host thread)
         o.pending.insert(o.pending.end(), p, p + len[j]);
@@ -274,21 +391,39 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
       for (uint32_t j = 0; j < k; j++) status[j] = MILZMA_INFRA_ERROR;
     return MILZMA_INFRA_ERROR;
   }
+  // What the crate's write() calls do with the data, cursor by cursor.  `first`: what Stream.tmp holds from a header that was read through it
+  // (a cursor of its own, in front of the data); `then`: the data.
+  std::vector<WriteCursor> first, then;
   for (uint32_t j = 0; j < k; j++) {
-    One& o = S->s[idx[j]];
+    const uint32_t i = idx[j];
+    One& o = S->s[i];
     o.write_err.clear();
+    o.taken = 0;
     if (len[j] == 0) continue;   // (write_all of nothing calls nobody: std::io::Write::write_all)
     switch (o.st) {
-      case One::FAILED:          // Stream.state is None: write() takes everything and does nothing (stream.rs:227-229, :324-325)
+      case One::FAILED:
+        // Stream.state is None (taken by the write that failed, stream.rs:230): write() does nothing and returns Ok(input.position()) =
+        // Ok(0) (stream.rs:324), which write_all turns into ErrorKind::WriteZero -- a dead stream refuses its bytes, it does not swallow them
+        refused[j] = len[j];
         break;
+      case One::SIDE: {
+        const uint32_t zero = 0;
+        if (milzma_streams_write_impl(o.side, 1, &zero, &data[j], &len[j], &st[j]) != MILZMA_OK) {
+          ctx->err = o.side->ctx->err;
+          side_failed = true;
+        }
+        o.write_err = o.side->s[0].write_err;
+        refused[j] = len[j] - std::min<uint64_t>(len[j], o.side->s[0].taken);
+        if (st[j] == MILZMA_IO_ERROR && refused[j] > 0 && o.write_err == "failed to write whole buffer") st[j] = MILZMA_OK;   // (said again below)
+        break;
+      }
       case One::DONE:
-        if (S->as_reader && S->kind == MILZMA_KIND_RAW_LZMA && S->units[idx[j]].unpacked_size == MILZMA_SIZE_UNKNOWN &&
-            S->res[idx[j]].status == MILZMA_ST_OK) {
+        if (S->as_reader && S->kind == MILZMA_KIND_RAW_LZMA && S->units[i].unpacked_size == MILZMA_SIZE_UNKNOWN && S->res[i].status == MILZMA_ST_OK) {
           // reader mode, a stream that ended with its END MARKER where a piece ended -- and the reader shows more: the one-shot call asks
           // the reader itself whether it is at its end (is_finished_ok, rangecoder.rs:49-52) and fails (lzma.rs:378-380)
-          milzma_result r = S->res[idx[j]];
+          milzma_result r = S->res[i];
           r.status = MILZMA_ST_MARKER_TRAILING;
-          r.out_flushed = r.out_len / S->units[idx[j]].dict_size * S->units[idx[j]].dict_size;   // (what the ring had flushed: lzbuffer.rs:264-267)
+          r.out_flushed = r.out_len / S->units[i].dict_size * S->units[i].dict_size;   // (what the ring had flushed: lzbuffer.rs:264-267)
           o.fail = r;
           o.has_fail = true;
           o.write_err = debug_lzma_error(r, S->kind);
@@ -296,25 +431,30 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
           st[j] = MILZMA_IO_ERROR;
           break;
         }
-        // the declared size is reached: write() takes nothing, write_all reports ErrorKind::WriteZero (lzma.rs:441-445; tests/lzma.rs:71-87).
-        // (Behind an end marker the reference would decode on from the marker's state; that is not followed: same answer.)
-        o.write_err = "failed to write whole buffer";
-        st[j] = MILZMA_IO_ERROR;
+        // the declared size is reached (an LZMA2 stream: its end byte is read; reader mode: the stream has ended): write() takes nothing,
+        // write_all reports ErrorKind::WriteZero (lzma.rs:441-445; tests/lzma.rs:71-87).  (A .lzma stream in Stream mode is never DONE
+        // by its end marker: it is parked behind it and decodes on, MILZMA_KIND_PARTIAL.)
+        refused[j] = len[j];
         break;
       case One::HEADER: {
         if (S->kind == MILZMA_KIND_LZMA2) {   // no header: the stream begins with its first packet
           milzma_unit u;
           memset(&u, 0, sizeof u);
           u.kind = MILZMA_KIND_LZMA2;
-          S->units[idx[j]] = u;
+          S->units[i] = u;
           o.st = One::DATA;
-          active.push_back(idx[j]);
+          then.push_back({j, i, o.pending.size(), 0});
           break;
         }
+        // The crate reads the header from the written data itself -- or, once an earlier write has left bytes in Stream.tmp, from THAT
+        // buffer, filled up to its 18 bytes (stream.rs:233-270): what it then holds behind the header and the range coder's five start
+        // bytes (up to 8 bytes, behind a five-byte header: UnpackedSize::UseProvided) stays there and is the next write() call's first input.
+        const bool via_tmp = before[j] > 0;
+        const size_t shown = via_tmp ? std::min<size_t>(o.pending.size(), 18) : o.pending.size();
         milzma_unit u;
         size_t hl = 0;
         milzma_output ho;
-        const int hr = milzma_lzma_read_header(o.pending.data(), o.pending.size(), &o.opt, &u, &hl, &ho);
+        const int hr = milzma_lzma_read_header(o.pending.data(), shown, &o.opt, &u, &hl, &ho);
         if (hr == MILZMA_HEADER_TOO_SHORT) break;   // need more data, try again later (stream.rs:185)
         if (hr != MILZMA_OK) {                      // fatal: LzmaError(s) => io::Error::new(Other, s) (stream.rs:291-299)
           const char* m = strchr(ho.msg, ':');
@@ -324,46 +464,61 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
           st[j] = MILZMA_IO_ERROR;
           break;
         }
-        if (o.pending.size() - hl < 5) break;       // RangeDecoder::new needs five bytes: Header again (stream.rs:176-180)
+        if (shown - hl < 5) break;                  // RangeDecoder::new needs five bytes: Header again (stream.rs:176-180)
+        if (uint32_t(u.lc) + u.lp > 3u && uint32_t(u.lc) + u.lp > (ctx->slab_live ? ctx->slab_lclp : ctx->slab_min_lclp) && S->n > 1) {
+          if (!to_side(S, i, before[j], &st[j])) side_failed = true;   // more literal rows than the batch's slab has per stream
+          refused[j] = len[j] - std::min<uint64_t>(len[j], o.taken);
+          if (st[j] == MILZMA_IO_ERROR && refused[j] > 0 && o.write_err == "failed to write whole buffer") st[j] = MILZMA_OK;   // (said again below)
+          break;
+        }
         o.hdr_len = hl;
         o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(hl));
         u.out_off = u.out_cap = 0;
-        S->units[idx[j]] = u;
+        S->units[i] = u;
         o.st = One::DATA;
-        active.push_back(idx[j]);
+        const size_t in_tmp = via_tmp ? shown - hl - 5 : 0;      // bytes Stream.tmp keeps behind the header and the five start bytes
+        const size_t rest = o.pending.size() - 5 - in_tmp;       // what write_all hands to the next write() call
+        if (in_tmp == 0) {
+          then.push_back({j, i, rest, 0});
+        } else if (rest == 0) {
+          o.in_tmp = in_tmp;   // nothing is decoded yet: Stream.tmp is looked at by the next write (stream.rs:312-317), or by finish
+        } else {
+          first.push_back({j, i, in_tmp, 5 + in_tmp});
+          then.push_back({j, i, rest, 0});
+        }
         break;
       }
       case One::DATA:
-        active.push_back(idx[j]);
+        if (o.in_tmp) {   // Stream.tmp first (a header read through it had left bytes there): a write() call of its own
+          first.push_back({j, i, o.in_tmp, 5 + o.in_tmp});
+          o.in_tmp = 0;
+        }
+        then.push_back({j, i, len[j], 0});
         break;
     }
   }
-  if (!active.empty() && !feed_round(S, active, false)) {
+  bool ok = !side_failed && run_cursors(S, first, st, nullptr);   // (what Stream.tmp held and the stream did not take is dropped: stream.rs:316)
+  if (ok) {
+    std::vector<WriteCursor> go;
+    for (const WriteCursor& c : then) {
+      One& o = S->s[c.i];
+      if (o.st == One::DONE) refused[c.j] = c.data;   // it ended inside Stream.tmp's bytes: read_data returns at once, nothing is taken
+      if (o.st == One::DATA) go.push_back(c);         // (else: failed there)
+    }
+    ok = run_cursors(S, go, st, &refused);
+  }
+  if (!ok) {
     if (status)
       for (uint32_t j = 0; j < k; j++) status[j] = MILZMA_INFRA_ERROR;
     return MILZMA_INFRA_ERROR;
   }
   for (uint32_t j = 0; j < k; j++) {
-    const uint32_t i = idx[j];
-    One& o = S->s[i];
-    if (o.st != One::DATA || !seen[i] || len[j] == 0) continue;
-    const milzma_result& r = S->res[i];
-    if (parked(r)) continue;
-    if (r.status == MILZMA_ST_OK || r.status == MILZMA_ST_SIZE_MISMATCH) {
-      // the stream has ended (its size is reached, or its end marker has been read with nothing behind it): Partial mode leaves its loop;
-      // "Expected unpacked size ..." is a check of finish() (lzma.rs:513-521, Finish mode only)
-      o.st = One::DONE;
-      if (!o.pending.empty()) {
-        o.write_err = "failed to write whole buffer";
-        st[j] = MILZMA_IO_ERROR;
-      }
-    } else {
-      o.write_err = debug_lzma_error(r, S->kind);
-      o.fail = r;
-      o.has_fail = true;
-      o.st = One::FAILED;
+    One& o = S->s[idx[j]];
+    if (st[j] == MILZMA_OK && refused[j] > 0) {
+      o.write_err = "failed to write whole buffer";
       st[j] = MILZMA_IO_ERROR;
     }
+    o.taken = len[j] - std::min<uint64_t>(len[j], refused[j]);
   }
   if (status)
     for (uint32_t j = 0; j < k; j++) status[j] = st[j];
@@ -403,6 +558,7 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     const uint32_t i = uint32_t(ii);
     One& o = S->s[i];
     milzma_output* out = &outs[i];
+    if (o.st == One::SIDE) return;   // (below: a batch of its own)
     if (o.st == One::HEADER) {
       if (S->as_reader) return;   // (done below, one after the other: it uses the context)
       if (!o.pending.empty()) out_fail(out, MILZMA_LZMA_ERROR, "failed to read header");   // stream.rs:122-128
@@ -445,6 +601,11 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
         else
           milzma_lzma_decompress_impl(ctx, o.pending.data(), o.pending.size(), &o.opt, &outs[i]);
       }
+  for (uint32_t i = 0; i < S->n; i++)
+    if (S->s[i].st == One::SIDE && milzma_streams_finish_impl(S->s[i].side, &outs[i]) != MILZMA_OK) {
+      ctx->err = S->s[i].side->ctx->err;
+      worst = MILZMA_INFRA_ERROR;
+    }
   bool copies_ok = true;
   for (uint32_t i = 0; i < S->n && copies_ok; i++)
     if (has[i] && outs[i].len)
@@ -472,8 +633,53 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
   return worst;
 }
 
+// Stream::get_output (stream.rs:102-116): what the sink of stream i holds right now.  State::Header: the sink as it was given -- nothing;
+// State::Data: what the ring has flushed (LzCircularBuffer::append_literal, lzbuffer.rs:264-267: the whole buffer every time the cursor
+// reaches dict_size; an LZMA2 stream's accumulating buffer: everything in front of its last dictionary reset); after a failed write the
+// crate's state is None and get_output answers None: *has_sink = 0.
+MILZMA_HIDDEN int milzma_streams_output_impl(milzma_streams* S, uint32_t stream, uint64_t offset, void* dst, size_t cap, uint64_t* sink_len,
+                                            int32_t* has_sink) {
+  if (!S || stream >= S->n) return MILZMA_INFRA_ERROR;
+  milzma_ctx* ctx = S->ctx;
+  ctx->err.clear();
+  if (S->finished) {
+    ctx->err = "the streams have been finished";
+    return MILZMA_INFRA_ERROR;
+  }
+  const One& o = S->s[stream];
+  if (o.st == One::SIDE) {
+    const int rc = milzma_streams_output_impl(o.side, 0, offset, dst, cap, sink_len, has_sink);
+    if (rc != MILZMA_OK) ctx->err = o.side->ctx->err;
+    return rc;
+  }
+  uint64_t len = 0;
+  if (o.st != One::HEADER && o.st != One::FAILED && o.started) {
+    const milzma_result& r = S->res[stream];
+    if (S->kind == MILZMA_KIND_RAW_LZMA)   // the ring's flushes (finish() brings the rest)
+      len = r.out_len / std::max<uint32_t>(S->units[stream].dict_size, 0x1000u) * std::max<uint32_t>(S->units[stream].dict_size, 0x1000u);
+    else   // (a parked unit's result carries its dict_base there; one that has ended, everything)
+      len = r.out_flushed;
+    len = std::min<uint64_t>(len, S->units[stream].out_cap);
+  }
+  if (has_sink) *has_sink = o.st == One::FAILED ? 0 : 1;
+  if (sink_len) *sink_len = o.st == One::FAILED ? 0 : len;
+  if (o.st == One::FAILED || !dst || cap == 0 || offset >= len) return MILZMA_OK;
+  const size_t take = size_t(std::min<uint64_t>(cap, len - offset));
+  if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
+      !hip_ok(ctx, hipMemcpyAsync(dst, static_cast<const uint8_t*>(S->out.p) + S->units[stream].out_off + offset, take, hipMemcpyDeviceToHost, work_stream(ctx)),
+              "D2H sink") ||
+      !hip_ok(ctx, hipStreamSynchronize(work_stream(ctx)), "hipStreamSynchronize"))
+    return MILZMA_INFRA_ERROR;
+  return MILZMA_OK;
+}
+
 MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S) {
   if (!S) return;
+  for (One& o : S->s)
+    if (o.side) {
+      milzma_streams_close_impl(o.side);
+      o.side = nullptr;
+    }
   if (S->ctx) {
     (void)hipSetDevice(S->ctx->device);
     dev_release(S->out);
@@ -484,7 +690,11 @@ MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S) {
 
 MILZMA_HIDDEN const char* milzma_streams_write_error_impl(const milzma_streams* S, uint32_t stream) {
   if (!S || stream >= S->n) return "";
-  return S->s[stream].write_err.c_str();
+  return S->s[stream].write_err.c_str();   // (a SIDE stream's text is copied over by every write)
+}
+
+MILZMA_HIDDEN uint64_t milzma_streams_write_taken_impl(const milzma_streams* S, uint32_t stream) {
+  return S && stream < S->n ? S->s[stream].taken : 0;
 }
 
 MILZMA_HIDDEN const char* milzma_streams_last_error_impl(const milzma_streams* S) { return S && S->ctx ? S->ctx->err.c_str() : "no streams"; }

@@ -1535,6 +1535,7 @@ struct orc_stream {
   lzbuf_t output;
   uint8_t partial[ORC_MAX_REQUIRED_INPUT]; /* DecoderState.partial_input_buf */
   size_t partial_pos;
+  size_t last_taken; /* test aid: the Ok(n) of Stream::write summed over the last write_all */
 };
 
 /* Stream::new_with_options, stream.rs:88-101 */
@@ -1656,6 +1657,7 @@ static int stream_write(orc_stream *s, const uint8_t *data, size_t len, size_t *
 int orc_stream_write_all(orc_stream *s, const uint8_t *data, size_t len, char *msg) {
   err_t e;
   memset(&e, 0, sizeof e);
+  s->last_taken = 0;
   while (len > 0) {
     size_t n = 0;
     if (stream_write(s, data, len, &n, &e)) {
@@ -1668,16 +1670,23 @@ int orc_stream_write_all(orc_stream *s, const uint8_t *data, size_t len, char *m
     }
     data += n;
     len -= n;
+    s->last_taken += n;
   }
   msg[0] = 0;
   return 0;
 }
 
-/* Stream::get_output, stream.rs:104-109: what the sink holds so far */
+/* how many bytes the last orc_stream_write_all got rid of before it returned (all of them on success) */
+size_t orc_stream_last_taken(const orc_stream *s) { return s->last_taken; }
+
+/* Stream::get_output, stream.rs:102-107: what the sink holds so far */
 size_t orc_stream_output(const orc_stream *s, const uint8_t **p) {
   *p = s->sink.data;
   return s->sink.len;
 }
+
+/* ... is_some() of it: `self.state.as_ref().map(..)` -- None once a write has failed (the state was taken, stream.rs:230) */
+int orc_stream_has_output(const orc_stream *s) { return s->state != 2; }
 
 /* Stream::finish, stream.rs:119-150; frees the stream.  res->out = what the sink holds (Ok: the whole output; Err: the reference drops W). */
 int orc_stream_finish(orc_stream *s, orc_result *res) {

@@ -107,12 +107,15 @@ int64_t orc_bench_lzma_batch(const uint8_t *in_base, const uint64_t *in_off,
  *   orc_stream_new        Stream::new_with_options (stream.rs:88-101); allow_incomplete = Options.allow_incomplete
  *   orc_stream_write_all  io::Write::write_all over Stream::write (stream.rs:223-326): 0, or ORC_IO_ERROR with msg (384 bytes) = the
  *                         io::Error's Display text (no "io error: " prefix: it is not an error::Error)
- *   orc_stream_output     Stream::get_output (stream.rs:104-109): the sink so far
+ *   orc_stream_output     Stream::get_output (stream.rs:102-107): the sink so far; orc_stream_has_output: whether the crate answers
+ *                         Some(..) (0 once a write has failed: the state was taken, stream.rs:230)
  *   orc_stream_finish     Stream::finish (stream.rs:119-150); frees the stream */
 typedef struct orc_stream orc_stream;
 orc_stream *orc_stream_new(const orc_options *opt, int allow_incomplete);
 int orc_stream_write_all(orc_stream *s, const uint8_t *data, size_t len, char *msg);
 size_t orc_stream_output(const orc_stream *s, const uint8_t **p);
+int orc_stream_has_output(const orc_stream *s);
+size_t orc_stream_last_taken(const orc_stream *s); /* bytes the last write_all handed to Stream::write with Ok(n) */
 int orc_stream_finish(orc_stream *s, orc_result *res);
 
 #ifdef __cplusplus

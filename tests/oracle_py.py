@@ -166,7 +166,17 @@ class Stream:
         if lib().orc_stream_write_all(self._h, bytes(data), len(data), msg) != 0:
             raise Stream.WriteError(msg.value.decode("utf-8", "replace"))
 
+    def last_taken(self):
+        """bytes the last write_all got rid of (the Ok(n) of Stream::write summed)"""
+        lib().orc_stream_last_taken.restype = ctypes.c_size_t
+        lib().orc_stream_last_taken.argtypes = [ctypes.c_void_p]
+        return lib().orc_stream_last_taken(self._h)
+
     def get_output(self):
+        """Stream::get_output: the sink's bytes, or None after a failed write"""
+        lib().orc_stream_has_output.argtypes = [ctypes.c_void_p]
+        if not lib().orc_stream_has_output(self._h):
+            return None
         p = ctypes.POINTER(ctypes.c_uint8)()
         n = lib().orc_stream_output(self._h, ctypes.byref(p))
         return ctypes.string_at(p, n) if n else b""

@@ -226,6 +226,49 @@ def test_emulated_loop_fed_in_views(loops, lc, lp, pb):
     assert r["status"] == "INPUT_EOF" and r["in_consumed"] + 13 == ref.in_consumed and r["out"][:len(ref.out)] == ref.out
 
 
+@pytest.mark.parametrize("lc,lp,pb", [(3, 0, 2), (1, 2, 1), (3, 0, 4), (4, 0, 2)])   # the LP0, GEN, PB4 and HBM variants of the loop
+def test_emulated_loop_goes_on_behind_an_end_marker(loops, lc, lp, pb):
+    """The crate's Partial mode at an end marker (lzma.rs:493-495, :507-509; MILZMA_KIND_PARTIAL): the loop of a write merely leaves at
+    `Finished`, and bytes written later are decoded on from the marker's state -- rep[0] = 0xFFFF_FFFF, the state after a match.  The
+    loop, re-entered from that state on a longer view, against the oracle's Stream fed the same two pieces."""
+    loop = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    rng = random.Random(4000 + lc * 100 + lp * 10 + pb)
+    plain = W.make_plain("text", 6000, seed=5)
+    head = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=False)
+    other = W.compress_alone(W.make_plain("text", 2000, seed=6), dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=False)
+    tails = [b"\x00" * 40, b"\xff" * 40, other[13:], head[13:], other, bytes([0, 0, 0, 0, 1]) + bytes(rng.randrange(256) for _ in range(200))]
+    tails += [bytes(rng.randrange(256) for _ in range(80)) for _ in range(24)]
+    seen = set()
+    for tail in tails:
+        o = orc.Stream()
+        o.write_all(head)
+        text = None
+        try:
+            o.write_all(tail)
+        except orc.Stream.WriteError as e:
+            text = str(e)
+        fin = o.finish()
+        if text is None:
+            text = fin.msg if not fin.ok else None
+        r = loop.decode_raw(head[13:] + tail, lc, lp, pb, 1 << 16, None, out_cap=1 << 20, feed_views=[len(head) - 13], partial=True)
+        assert len(r["feeds"]) >= 1 and r["feeds"][-1] == (len(head) - 13, len(head) - 13)     # parked right behind the marker
+        st = r["status"]
+        seen.add(st)
+        if st == "OK":
+            assert text is None and r["out"] == fin.out, (tail[:8], len(r["out"]), len(fin.out))
+            continue
+        want = {"MATCH_DIST_DICT": "Match distance %d is beyond dictionary size 65536" % (r["rep0"] + 1),
+                "LZ_DIST_DICT": "LZ distance %d is beyond dictionary size 65536" % (r["rep0"] + 1),
+                "MATCH_DIST_OUT": "Match distance %d is beyond output size %d" % (r["rep0"] + 1, r["len"]),
+                "LZ_DIST_OUT": "LZ distance %d is beyond output size %d" % (r["rep0"] + 1, r["len"]),
+                "MARKER_TRAILING": "Found end-of-stream marker but more bytes are available",
+                "INPUT_EOF": "failed to fill whole buffer"}[st]
+        assert text is not None and want in text, (tail[:8], st, text)
+    # (behind a marker `code` is 0 -- is_finished_ok demanded it --, so the next decision is_match always says "literal": a matched one, whose
+    #  match byte lies rep[0] + 1 = 2^32 back.  Whatever is written behind a marker ends there.)
+    assert seen == {"MATCH_DIST_DICT"}, seen
+
+
 def test_emulated_hbm_variant_lclp_above_four():
     """The HBM variant of the loop (lc + lp > 4: the 2^(lc+lp) literal rows in a slab in memory, eight register rows and eight LDS
     rows as direct-mapped caches over it, tags in two VGPRs' lanes): streams with real match structure for every kind of property set

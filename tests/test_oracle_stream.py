@@ -145,3 +145,48 @@ def test_bytes_behind_a_known_size_stream_are_a_write_zero_error():
     s.write_all(comp[:len(comp) - 6])     # (the six bytes of liblzma's end marker stay behind: the declared size is reached before them)
     with pytest.raises(orc.Stream.WriteError, match="failed to write whole buffer"):
         s.write_all(b"more bytes that nobody reads" * 2)
+
+
+def test_behind_an_end_marker_by_hand():
+    """What the crate does with bytes written BEHIND an end marker that ended a write, derived by hand from the source (no test of the
+    reference covers it): process_next returns Finished only after `rep[0] = 0xFFFF_FFFF` and the state after a match are in place
+    (lzma.rs:365-377), the Partial-mode loop merely `break`s (lzma.rs:493-495, :507-509) and Stream stays in State::Data.  is_finished_ok
+    demanded code == 0 (rangecoder.rs:48-50), so the next is_match decision finds code < bound: a literal (lzma.rs:287-292) -- in a state
+    >= 7, a matched one: `output.last_n(rep[0] + 1)` = last_n(2^32) (lzma.rs:540-541), beyond ANY dictionary (lzbuffer.rs:241-245).
+    With fewer than 20 bytes at hand the trial run fails on exactly that and the bytes wait in the partial-input buffer (lzma.rs:498-505);
+    the write that brings the 20th byte, or finish, reports it.  A dead stream then refuses every byte (stream.rs:230, :324: Ok(0))."""
+    text = 'LzmaError("Match distance 4294967296 is beyond dictionary size 8388608")'
+    s = orc.Stream()
+    s.write_all(EMPTY)
+    s.write_all(b"\x00" * 19)                                   # 19 bytes: the trial run fails, nothing is reported
+    assert s.last_taken() == 19 and s.get_output() == b""
+    with pytest.raises(orc.Stream.WriteError) as e:
+        s.write_all(b"\x00")                                    # the 20th
+    assert str(e.value) == text
+    assert s.get_output() is None                               # the state is gone, and the sink with it
+    with pytest.raises(orc.Stream.WriteError, match="failed to write whole buffer"):
+        s.write_all(b"x")
+    assert s.last_taken() == 0
+    r = s.finish()
+    assert not r.ok and r.msg == "lzma error: can't finish stream because of previous write error"
+    # ... reported by finish when fewer than 20 bytes followed (Finish mode takes no trial run, lzma.rs:462-481)
+    s = orc.Stream()
+    s.write_all(EMPTY)
+    s.write_all(b"\xaa" * 5)
+    r = s.finish()
+    assert not r.ok and r.msg == "lzma error: Match distance 4294967296 is beyond dictionary size 8388608"
+    # ... unless the caller allows an incomplete stream: no last pass at all (stream.rs:130-140)
+    s = orc.Stream(allow_incomplete=True)
+    s.write_all(EMPTY)
+    s.write_all(b"\xaa" * 5)
+    r = s.finish()
+    assert r.ok and r.out == b""
+    # bytes behind the marker in the SAME write: the range decoder's reader is not at its end (lzma.rs:375-381)
+    s = orc.Stream()
+    with pytest.raises(orc.Stream.WriteError, match="Found end-of-stream marker but more bytes are available"):
+        s.write_all(EMPTY + b"\x00")
+    # a provided size that the marker does not deliver: finish decodes on from the marker's state
+    s = orc.Stream(unpacked_size_mode=orc.READ_HEADER_BUT_USE_PROVIDED, provided=7)
+    s.write_all(EMPTY)
+    r = s.finish()
+    assert not r.ok and r.msg == "lzma error: Match distance 4294967296 is beyond dictionary size 8388608"

@@ -402,14 +402,19 @@ class AsmLoop:
             pos += hdr + packed
 
     # ---- the kernel around the loop (decode_fast_asm.hip.h), raw LZMA units only ------------------------------
-    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None, feed_views=None):
+    def decode_raw(self, payload, lc, lp, pb, dict_size, unpacked_size, out_cap=None, max_steps=1 << 40, hw_slot=0, quantum=None, feed_views=None,
+                   partial=False):
         """Returns dict(status, out, len, in_consumed, executed).  unpacked_size None = unknown (marker mode).
         quantum: output bytes after which the loop yields at the next symbol top (the time-sliced launches); the front end then does
         what the kernel's resume does (re-seeks the reader from its position, has the per-lane tables rebuilt) and re-enters.
         feed_views: ascending prefix lengths of `payload` -- the input arrives in VIEWS (MILZMA_DECODE_FEED): the loop runs with the FEED bit
         on the first feed_views[0] bytes, leaves with NEED_INPUT at a symbol top near the view's end, and is re-entered on the next, longer
         view (the reader re-seeked at its position, as the kernel's resume does); the whole payload comes last, without the bit.
-        The result then carries `feeds` = [(view length, reader position at the stop), ...]."""
+        The result then carries `feeds` = [(view length, reader position at the stop), ...].
+        partial (with feed_views): the crate's Partial mode at an END MARKER (MILZMA_KIND_PARTIAL, lzma.rs:493-495 / :507-509) the way the
+        time-sliced kernel does it: a view's tail (fewer than 20 bytes left) is decoded on as if the view were the last (the trial pass;
+        here without the roll-back: every symbol of the tail must be complete), and a marker that ends the view with code == 0 does not
+        end the unit -- the loop is re-entered on the next view from the marker's state."""
         G = self.G
         if out_cap is None:
             out_cap = unpacked_size if unpacked_size is not None else len(payload) * 64 + 4096
@@ -492,6 +497,7 @@ class AsmLoop:
         executed = 0
         status = None
         yields = 0
+        trial = False
         while True:
             S("qtop", min(0xFFFFFFFF, self.sget("len") + quantum) if quantum else 0xFFFFFFFF)
             n = self.L.emu_run(self.h, 0, max_steps)
@@ -500,11 +506,31 @@ class AsmLoop:
             executed += n
             ex = self.sget("exitcode") & 0xFF      # (bit 8: "re-seek before reading on" -- positions are right either way)
             S("exitcode", ex)
-            if ex == G.EXIT["NEED_INPUT"]:
+            marker_park = False
+            if partial and ex == G.EXIT["MARKER"] and len(views) > 1 and self.sget("state") in (7, 10):
+                rem = (self.sget("lim") - self.sget("off")) & 0xFFFFFFFF
+                marker_park = rem == 0 and self.sget("code") == 0      # AsmDecoder::process: parked behind the marker
+                if marker_park:
+                    S("mlen", 0)
+            if partial and ex == G.EXIT["NEED_INPUT"] and not trial:
+                # the view's tail: on as if the view were the last (no FEED bit), from the registers as they are
+                trial = True
+                v = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF
+                r = in_len - v
+                S("lc8", 8 - lc)
+                S("wbase", v & ~63)
+                S("off", v & 63)
+                S("lim", (v & 63) + r)
+                self.vset(self._vidx("winb"), window(v & ~63))
+                self.vset(self._vidx("winb_next"), window((v & ~63) + 64))
+                S("tbl_ready", 0)
+                continue
+            if ex == G.EXIT["NEED_INPUT"] or marker_park:
                 # MILZMA_DECODE_FEED: parked at a symbol top near the end of the view; the next view is longer (here: of the same buffer)
                 v = (self.sget("wbase") + self.sget("off")) & 0xFFFFFFFF
                 feeds.append((in_len, v))
                 assert len(views) > 1 and in_len - v < G.FEED_MARGIN, (in_len, v)
+                trial = False
                 views.pop(0)
                 payload = full_payload[:views[0]]
                 in_len = len(payload)
@@ -557,6 +583,9 @@ class AsmLoop:
                 status = ST_OK if ln == unpacked_size else "SIZE_MISMATCH"
             elif name == "DONE_FIN":
                 status = ST_OK
+            elif name == "MARKER" and self.sget("state") not in (7, 10):
+                # a REP match that finds the marker's distance in the history (only behind a marker, `partial`): append_lz's error
+                status = "LZ_DIST_DICT"
             elif name == "MARKER":
                 rem = (self.sget("lim") - self.sget("off")) & 0xFFFFFFFF
                 status = ST_OK if (rem == 0 and self.sget("code") == 0) else "MARKER_TRAILING"
@@ -572,7 +601,7 @@ class AsmLoop:
             in_consumed = (in_consumed - 1) & 0xFFFFFFFF
             assert in_consumed == in_len, (in_consumed, in_len)
         return dict(status=status, out=mem[OUT0:OUT0 + min(ln, out_cap)].tobytes(), len=ln, in_consumed=in_consumed,
-                    executed=executed, yields=yields, feeds=feeds)
+                    executed=executed, yields=yields, feeds=feeds, rep0=self.sget("rep0"))
 
     # ---- executed-instruction statistics ------------------------------------------------------------------
     def counts(self):

@@ -184,6 +184,69 @@ def pipes_table(emu, n, prices_path, cycles_per_byte, quiet=False):
     return hist, pipe
 
 
+def section_pipes_table(emu, n, prices_path, out_path, cycles_per_byte, a):
+    """per loop section and role, the cycles per output byte each ISSUE PIPE is busy for one wave -- every executed
+    instruction at the measured issue cost of its form (profiles/r05_pipe_prices.json), scalar ALU, branch unit (a taken branch costs
+    `taken_extra` more) and vector ALU apart.  The scalar column (salu + branch) is the work list while the scalar pipe binds."""
+    import json
+    prices = json.load(open(prices_path))
+    c, tk = emu.counts()
+    tab, instr = {}, {}
+    for i, text in enumerate(emu.prog.text):
+        if not c[i]:
+            continue
+        f = form_of(text)
+        cls = "valu" if f.startswith("v_") else "branch" if f.startswith(("s_cbranch", "s_branch", "s_setpc", "s_call")) else "salu" if f.startswith("s_") else None
+        if cls is None:
+            continue
+        pr = prices["forms"].get(f, prices["forms"].get(f.split("/")[0]))
+        if pr is None:
+            pr = prices["default"][cls]
+        sec, role = emu.prog.tag[i]
+        key = (sec or "?", role or "book")
+        d = tab.setdefault(key, {"salu": 0.0, "branch": 0.0, "valu": 0.0})
+        d[cls] += pr * int(c[i]) + (prices.get("taken_extra", 0.0) * int(tk[i]) if cls == "branch" else 0.0)
+        e = instr.setdefault(key, {"salu": 0, "branch": 0, "valu": 0, "taken": 0})
+        e[cls] += int(c[i])
+        e["taken"] += int(tk[i])
+    secs = {}
+    for (sec, role), d in tab.items():
+        s_ = secs.setdefault(sec, {"salu": 0.0, "branch": 0.0, "valu": 0.0})
+        for k in d:
+            s_[k] += d[k]
+    print("%-18s %-9s | %9s %9s %9s | %8s %8s %8s %8s" % ("section", "role", "salu c/B", "branch c/B", "valu c/B", "salu /B", "branch/B", "taken/B", "valu /B"))
+    rows = {}
+    for sec, s_ in sorted(secs.items(), key=lambda kv: -(kv[1]["salu"] + kv[1]["branch"])):
+        print("%-18s %-9s | %9.2f %9.2f %9.2f |" % (sec, "all", s_["salu"] / n, s_["branch"] / n, s_["valu"] / n))
+        rows[sec] = {"pipe_cycles_per_byte": {k: round(v / n, 3) for k, v in s_.items()}, "roles": {}}
+        for role in ROLES:
+            d = tab.get((sec, role))
+            if not d:
+                continue
+            e = instr[(sec, role)]
+            print("%-18s %-9s | %9.2f %9.2f %9.2f | %8.3f %8.3f %8.3f %8.3f" % ("", role, d["salu"] / n, d["branch"] / n, d["valu"] / n, e["salu"] / n,
+                                                                            e["branch"] / n, e["taken"] / n, e["valu"] / n))
+            rows[sec]["roles"][role] = {"pipe_cycles_per_byte": {k: round(v / n, 3) for k, v in d.items()},
+                                        "instructions_per_byte": {k: round(v / n, 4) for k, v in e.items()}}
+    tot = {k: sum(s_[k] for s_ in secs.values()) / n for k in ("salu", "branch", "valu")}
+    print("%-18s %-9s | %9.2f %9.2f %9.2f |" % ("all", "", tot["salu"], tot["branch"], tot["valu"]))
+    if cycles_per_byte:
+        print("at four waves per SIMD and %.0f cycles per byte per wave: scalar pipe (salu + branch) %.1f %% busy, vector pipe %.1f %%"
+              % (cycles_per_byte, 400.0 * (tot["salu"] + tot["branch"]) / cycles_per_byte, 400.0 * tot["valu"] / cycles_per_byte))
+    if out_path:
+        import bench
+        with open(out_path, "w") as f:
+            json.dump({"kernel_source_sha256": bench.kernel_source_hash(),
+                       "workload": "%s, %d streams of %d B (indices %d..%d of bench.py's recipe), dict %d"
+                                   % (a.kind, a.streams, a.size, a.index, a.index + a.streams - 1, a.dict),
+                       "how": "tools/emu/profile.py --section-pipes: the generated loop executed on the CPU emulator (bit-exact output); every "
+                              "executed instruction attributed to its loop section and role and priced at the measured issue cost of its form "
+                              "(profiles/r05_pipe_prices.json): cycles per output byte each issue pipe is busy for ONE wave",
+                       "cycles_per_byte_per_wave": cycles_per_byte or None,
+                       "all": {k: round(v, 3) for k, v in tot.items()}, "sections": rows}, f, indent=1)
+            f.write("\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1 << 20)
@@ -193,6 +256,7 @@ def main():
     ap.add_argument("--index", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="average over this many streams (indices index .. index + streams - 1)")
     ap.add_argument("--sections", default="", help="write the per-section / per-role table (instructions per output byte) to this JSON file and print it")
+    ap.add_argument("--section-pipes", default=None, nargs="?", const="", help="per section and role: cycles per byte each issue pipe is busy (optionally written to this JSON file)")
     ap.add_argument("--cost", action="store_true", help="estimated cycles per output byte by section, from the measured price of each kind of instruction")
     ap.add_argument("--pipes", action="store_true", help="executed instructions by opcode form; with --prices: pipe cycles per byte")
     ap.add_argument("--prices", default=os.path.join(ROOT, "profiles", "r05_pipe_prices.json"))
@@ -268,6 +332,8 @@ def main():
         sections_table(emu, n, a, executed)
     if a.cost:
         cost_table(emu, n)
+    if a.section_pipes is not None:
+        section_pipes_table(emu, n, a.prices, a.section_pipes, a.cycles_per_byte, a)
 
     if a.regions:
         c, tk = emu.counts()

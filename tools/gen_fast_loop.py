@@ -177,6 +177,10 @@ PRESYMV = os.environ.get("MILZMA_GEN_PRESYMV", "0") == "1"
 #   ALIGN_STUBS: log2 of the alignment of out-of-line branch targets that are only ever reached by a taken branch (the normalisation stubs: 0.74 taken
 #       branches per byte go in and out of them) -- the padding in front of such a label is never executed
 ALIGN_STUBS = int(os.environ.get("MILZMA_GEN_ALIGN_STUBS", "0"))
+#   ALIGN_FREE (round 6): log2 of the alignment of EVERY label that cannot be fallen into (the instruction in front of it is an unconditional branch /
+#       s_setpc): the padding is never executed, so taken-branch targets -- the loop top after a literal, `match`, the rep branches, the stubs, the
+#       out-of-line paths -- start a fetch line for free.  (Not inside the direct-bit chains: their entries are computed from equal strides.)
+ALIGN_FREE = int(os.environ.get("MILZMA_GEN_ALIGN_FREE", "0"))
 K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 # Where the loop's code falls in the 32-byte instruction fetch lines is worth +-1.2 % (round 5, profiles/r05_kernel_ab.txt section 4: the loop 64-byte
@@ -327,6 +331,7 @@ class Gen:
         self.lazy = self.split and ALIGNLAZY
         self.sq = []          # scalar (or index-mode) instructions for the next decision's shadow (SSHADOW): straight-line code only
         self.reach = True
+        self.no_align = False   # (inside the direct-bit chains: ALIGN_FREE must not touch their layout)
         self.lstate = {}
         self.sec, self.role = "prologue", "book"   # attribution of what is emitted (profiling only)
 
@@ -388,6 +393,8 @@ class Gen:
             if reg is None:
                 reg = self.lstate[name] = ()
             self.q = list(reg)
+        if ALIGN_FREE and not self.reach and not self.no_align and not name.startswith(("dchain", "dend", "dtr_", "db_", "dn_", "DN")):
+            self.cur.append(".p2align %d" % ALIGN_FREE)
         self.reach = True
         self.cur.append("L%s%%=:" % name)
 
@@ -1462,6 +1469,7 @@ class Gen:
             self.lstate[name] = self._st()
         e("s_setpc_b64 " + JPAIR)
         self.sec = "direct bits"
+        self.no_align = True
         if DIRECT8:
             for v in range(8):
                 lab("dchain%d" % v)
@@ -1487,6 +1495,7 @@ class Gen:
             for _ in range(26):
                 self.direct_bit(R("t4"))
         self.sec = "align"
+        self.no_align = False
         lab("direct_done")
         written = False
         for i in range(4):
@@ -2045,11 +2054,25 @@ class Gen:
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
+# MIXV (tuning build, round 6: VERDICT r5 item 2d "per-wave mixing"): a fifth instance of the loop, LP0V = LP0 with the tree walks' range < 2^24
+# test on the vector ALU (v_cmp + s_cbranch_vccnz: one scalar instruction less per tree decision, one vector instruction more).  The kernel built
+# with -DMILZMA_MIXV runs it on the waves in slot 0 of their SIMD (one wave in four), the other three keep the scalar test: the four waves of a
+# SIMD share its vector pipe and its turn on the CU's scalar pipe, so a mix of forms shifts load between the pipes without every wave paying.
+MIXV = os.environ.get("MILZMA_GEN_MIXV", "0") == "1"
+
+
 def main():
+    global NORM_S, VB2_INLINE
     texts, clobbers, fixeds = {}, {}, {}
-    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)):
+    variants = [("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)] + ([("LP0V", True, False)] if MIXV else [])
+    for name, lp0, pb4 in variants:
+        saved = (NORM_S, VB2_INLINE)
+        if name == "LP0V":
+            NORM_S = NORM_S - {"tree"}
+            VB2_INLINE = DISP2 and not NORM_S >= {"tree", "single", "lit", "direct"}
         g = Gen(lp0, pb4, hbm=(name == "HBM"))
         g.build()
+        NORM_S, VB2_INLINE = saved
         lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
         g.finish()
