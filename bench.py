@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 CUS, CLOCK_GHZ = 256, 2.4
-PROFILE_ROUND = "r05"   # profiles/<round>_pmc_<config>.json and _instruction_mix_<config>.json are read only if their kernel hash is this build's
+PROFILE_ROUND = "r06"   # profiles/<round>_pmc_<config>.json and _instruction_mix_<config>.json are read only if their kernel hash is this build's
 
 PROPS = (3, 0, 2)  # lc, lp, pb of the generated .lzma streams (--props; the forked compression workers inherit it)
 
@@ -267,13 +267,22 @@ def cpu_baseline(size, kind, dict_size, cores):
     # (which releases the GIL while decoding)
     import lzma
     from concurrent.futures import ThreadPoolExecutor
+    # (liblzma refuses a known-size header on a stream that also carries the end marker, SURVEY A.8: give it
+    #  the header the encoder wrote, size field all ones)
+    native = [c[:5] + b"\xff" * 8 + c[13:] for c in comps]
+    xz_times, xz_passes = [], 1
     with ThreadPoolExecutor(cores) as ex:
-        t0 = time.time()
-        # (liblzma refuses a known-size header on a stream that also carries the end marker, SURVEY A.8: give it
-        #  the header the encoder wrote, size field all ones)
-        got = sum(ex.map(lambda c: len(lzma.decompress(c[:5] + b"\xff" * 8 + c[13:], format=lzma.FORMAT_ALONE)), comps))
-        dt_xz = time.time() - t0
-    assert got == n_all * size
+        def xz_run(passes):
+            t0 = time.time()
+            got = sum(ex.map(lambda c: len(lzma.decompress(c, format=lzma.FORMAT_ALONE)), native * passes))
+            assert got == n_all * size * passes
+            return time.time() - t0
+        t_probe = xz_run(1)                                   # (also the warm-up)
+        xz_passes = max(1, int(5.0 / max(t_probe, 1e-3)) + 1)   # every timed run lasts at least 5 s (r5: one run of ~1 s spread 37 % between boxes)
+        for _ in range(3):
+            xz_times.append(xz_run(xz_passes))
+    dt_xz = statistics.median(xz_times)
+    got = n_all * size * xz_passes
     return {"value": round(many, 4), "unit": "GB/s decompressed", "cores": cores, "kind": "port",
             "host": {"logical_cpus": os.cpu_count(), "usable_cpus": cores,
                      "note": "the box exposes %s hardware threads; the container's cgroup quota grants %d of them, and that is what every CPU "
@@ -285,7 +294,8 @@ def cpu_baseline(size, kind, dict_size, cores):
                            "sample": "%d streams of the same sample, median of 3 runs (%.2f s each)" % (max(8, min(32, n_all)), t_one)},
             "liblzma": {"value": round(got / dt_xz / 1e9, 4), "unit": "GB/s decompressed", "cores": cores,
                         "note": "liblzma via Python lzma.decompress on the same sample (not the reference; an "
-                                "independent, faster CPU decoder)"}}
+                                "independent, faster CPU decoder); median of 3 runs of %d passes over the sample (%.1f s each)"
+                                % (xz_passes, dt_xz)}}
 
 
 
@@ -303,6 +313,15 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash, units=4096):
     if mix.get("kernel_source_sha256") != khash or not pc:
         return None
     pb = mix["per_output_byte"]
+    # ... and the same pipes as the hardware counters saw them (profiles/<round>_pmc_<config>.json, same rule as `traffic`: only a record taken
+    # on exactly this kernel source counts, else null)
+    pmc_busy = None
+    pmc_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_%s.json" % config)
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            rec = json.load(f)
+        if rec.get("kernel_source_sha256") == khash:
+            pmc_busy = rec.get("derived", {}).get("pipe_busy_from_counters")
     waves_per_simd = min(units, CUS * 16) / float(CUS * 4)          # one wave per unit, 16 resident waves per CU
     cyc = k_ms * 1e-3 * CLOCK_GHZ * 1e9 / (out_bytes / float(units)) # cycles one output byte takes a wave
     busy = {k: waves_per_simd * pc[k] / cyc for k in ("valu", "salu", "branch")}
@@ -311,6 +330,7 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash, units=4096):
             "unit": "busy fraction of the pipe", "peak": 1.0, "achieved": round(max(busy["valu"], sb), 4), "frac": round(max(busy["valu"], sb), 4),
             "valu_busy": round(busy["valu"], 4), "salu_busy": round(busy["salu"], 4), "branch_busy": round(busy["branch"], 4),
             "salu_plus_branch_busy": round(sb, 4), "binding_pipe": "valu" if busy["valu"] > sb else "salu+branch",
+            "pmc": pmc_busy,
             "pipe_cycles_per_output_byte_per_wave": pc, "cycles_per_output_byte_per_wave": round(cyc, 1), "waves_per_simd": waves_per_simd,
             "clock_ghz": CLOCK_GHZ,
             "instructions_per_output_byte": pb["total"], "salu_per_output_byte": pb["salu"],
@@ -856,7 +876,7 @@ def main():
     procs = max(1, cores // world)
     distinct = n if args.distinct == 0 else min(n, cfg["distinct"] if args.distinct < 0 else args.distinct)
     # host-side generation first (forks worker processes): before any HIP/RCCL state exists
-    scatter = args.scatter and world > 1
+    scatter = args.scatter and (world > 1 or D.forced())   # (MILZMA_DIST_FORCE=1: the process group and the scatter / gather path at world size 1)
     shares = None
     if scatter:
         # north_star: "RCCL ... only for input scatter and output gather".  Rank 0 is the node's ingest point: it holds a pool of
@@ -970,6 +990,8 @@ def main():
     table = D.all_ranks([statistics.median(kernel_ms), float(D.device_identity(dev_index))], dev)
     per_rank_kernel_ms = [round(r[0], 3) for r in table]
     distinct_devices = len({int(r[1]) for r in table})
+    if any(int(r[1]) == 0 for r in table):   # no physical identity to be had (distributed.device_identity): nothing to hold against the run
+        distinct_devices = world
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
     if distinct_devices < world and os.environ.get("MILZMA_DIST_BACKEND") != "gloo":
         raise SystemExit("bench.py --gpus %d: the %d ranks ran on %d distinct GPU(s); refusing to print a scaling number" % (world, world, distinct_devices))

@@ -517,7 +517,9 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     if (is_fast) {
       const uint32_t resident = fast_resident_blocks(ctx->lds_pad);
       // (growable output is a feature of the time-sliced kernel: it is the one that can park a unit)
-      const bool want_stream = ctx->stream_span != 0 && (ctx->stream_host != nullptr || ctx->stream_ptrs != nullptr) && m == ctx->pend_n && !resume;  // (the launch is the whole batch: the counters reach n)
+      // (the launch is the whole batch: the counters reach n -- or nobody counts: stream_feed)
+      const bool want_stream = ctx->stream_span != 0 && (ctx->stream_host != nullptr || ctx->stream_ptrs != nullptr) &&
+                               ((m == ctx->pend_n && !resume) || ctx->stream_feed);
       sliced = grow || want_stream || ctx->slice_mode > 0 || (ctx->slice_mode == 0 && m > resident && m % resident != 0);
       if (sliced) {
         uint64_t entries = m, longest = 0;

@@ -147,6 +147,8 @@ struct milzma_ctx {
   const uint64_t* stream_ptrs = nullptr;  // ... or, per unit, the caller's own page-locked result buffer (device array in `hostptrs`)
   bool stream_in_host = false;      // ... and its input is read from host memory that is still being filled (progress[kMaxSpans] = ready)
   bool stream_active = false;
+  bool stream_feed = false;         // ... for EVERY time-sliced launch of the call, resuming ones too (push-mode streams: nobody waits on the span
+                                    // counters, the waves just deliver what they decode into the units' result buffers, host_stream.cpp)
   PinBuf pin_results;
   hipStream_t copy_stream = nullptr;    // chunked staging copies of the whole-file batch entry points
   hipStream_t work_stream = nullptr;    // decode launches of the whole-file / host-buffer entry points: the context's own

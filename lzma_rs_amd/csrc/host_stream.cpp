@@ -40,6 +40,15 @@ struct One {
   size_t in_tmp = 0;               // bytes (pending[5 .. 5 + in_tmp)) that the crate holds in Stream.tmp behind a header it read through that
                                    // buffer: its next write() call's first input (stream.rs:312-317); the unit has not started yet
   size_t view = 0;                 // feed_round: only this much of `pending` is the unit's view (0: all of it)
+  // The stream's RESULT buffer (page-locked, from the pool: what finish hands over), filled by the decoding waves themselves while they
+  // decode -- every turn's bytes go over PCIe under the kernel (kernels.h: host_ptrs), finish has nothing left to copy.
+  uint8_t* hbuf = nullptr;
+  size_t hcap = 0;
+  // For the length of one write call: bytes that follow `pending` but still lie in the CALLER's buffer (a running stream's data go from
+  // there straight into the upload buffer; only what the decoder leaves unused is kept)
+  const uint8_t* ext = nullptr;
+  size_t ext_len = 0;
+  size_t held() const { return pending.size() + ext_len; }
   // reader mode (MILZMA_STREAMS_AS_READER): what the failed decode itself said, for finish to hand over instead of Stream::finish's
   // "previous write error"
   bool has_fail = false;
@@ -72,6 +81,7 @@ struct milzma_streams {
   // the crate's Partial mode at an end marker (MILZMA_KIND_PARTIAL): .lzma streams in Stream mode.  (Reader mode stands for the one-shot
   // call, whose range decoder asks the READER whether it is at its end; LZMA2 streams end at their end byte.)
   bool partial() const { return kind == MILZMA_KIND_RAW_LZMA && !as_reader; }
+  bool deliver = false;        // the waves write every stream's output into its result buffer while they decode (One::hbuf)
 };
 
 MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint32_t n, const milzma_options* options, milzma_streams** out);
@@ -118,6 +128,32 @@ static bool regrow(milzma_streams* S, const std::vector<std::pair<uint32_t, uint
     S->units[i].out_off = off[i];
     S->units[i].out_cap = cap[i];
   }
+  if (S->deliver) {   // the result buffers follow the slices (what has been delivered moves along: rare -- the first guess is generous)
+    std::atomic<int> failed{0};
+    parallel_for(want.size(), [&](size_t w) {
+      const uint32_t i = want[w].first;
+      One& o = S->s[i];
+      if (o.hcap >= cap[i]) return;
+      uint8_t* nb = out_alloc(size_t(cap[i]), true);
+      if (!nb) {
+        failed.store(1);
+        return;
+      }
+      const size_t have = o.hbuf ? size_t(std::min<uint64_t>(S->res[i].out_len, o.hcap)) : 0;
+      if (have) memcpy(nb, o.hbuf, have);
+      if (o.hbuf) milzma_free(o.hbuf);
+      o.hbuf = nb;
+      o.hcap = size_t(cap[i]);
+    });
+    if (failed.load()) {   // page-locked memory has run out: from here on finish copies (what was delivered so far is on the device too)
+      S->deliver = false;
+      for (One& o : S->s) {
+        if (o.hbuf) milzma_free(o.hbuf);
+        o.hbuf = nullptr;
+        o.hcap = 0;
+      }
+    }
+  }
   return true;
 }
 
@@ -132,8 +168,9 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
     for (uint32_t i : active)
       if (!S->s[i].started) {
         const milzma_unit& u = S->units[i];
-        const uint64_t plausible = std::max<uint64_t>(uint64_t(1) << 20, uint64_t(S->s[i].pending.size()) * 1024);
-        uint64_t cap = std::max<uint64_t>(1 << 16, uint64_t(S->s[i].pending.size()) * 8);
+        const uint64_t plausible = std::max<uint64_t>(uint64_t(1) << 20, uint64_t(S->s[i].held()) * 1024);
+        // (no size declared: 8 x what has arrived -- 16 x where the waves deliver into result buffers, which a regrow would have to copy)
+        uint64_t cap = std::max<uint64_t>(1 << 16, uint64_t(S->s[i].held()) * (S->deliver ? 16 : 8));
         if (u.unpacked_size != MILZMA_SIZE_UNKNOWN) cap = std::min<uint64_t>(u.unpacked_size, plausible) + 512;
         if (u.memlimit < u.dict_size) cap = std::min<uint64_t>(cap, u.memlimit + 512);   // (ends at memlimit bytes: lzbuffer.rs:206-217)
         want.emplace_back(i, cap);
@@ -157,16 +194,26 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
     size_t in_total = 0;
     for (uint32_t i : active) {
       is_active[i] = 1;
-      const size_t view = S->s[i].view ? std::min(S->s[i].view, S->s[i].pending.size()) : S->s[i].pending.size();
+      const size_t view = S->s[i].view ? std::min(S->s[i].view, S->s[i].held()) : S->s[i].held();
       S->units[i].in_off = in_total;
       S->units[i].in_len = view;
       in_total += round_up(view, 64) + 64;
     }
-    if (!pin_reserve(ctx, ctx->pin_in, in_total + 512) || !dev_reserve(ctx, ctx->in, in_total + 512)) return false;
+    trace_mark(ctx, "streams: round begins");
+    // (with headroom when they must grow: the next call's views are a few bytes longer -- what the streams left unused comes in front of
+    //  the new data --, and re-pinning 400 MB for them was 40 ms of a write call)
+    const size_t need = in_total + 512;
+    if ((ctx->pin_in.cap < need && !pin_reserve(ctx, ctx->pin_in, need + need / 4)) || (ctx->in.cap < need && !dev_reserve(ctx, ctx->in, need + need / 4)))
+      return false;
     parallel_for(active.size(), [&](size_t a) {
       const uint32_t i = active[a];
-      if (S->units[i].in_len) memcpy(static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off, S->s[i].pending.data(), size_t(S->units[i].in_len));
+      One& o = S->s[i];
+      uint8_t* dst = static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off;
+      const size_t view = size_t(S->units[i].in_len), own = std::min(view, o.pending.size());
+      if (own) memcpy(dst, o.pending.data(), own);
+      if (view > own) memcpy(dst + own, o.ext, view - own);
     });
+    trace_mark(ctx, "streams: views gathered");
     if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
         !hip_ok(ctx, hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_total, hipMemcpyHostToDevice, work_stream(ctx)), "H2D views"))
       return false;
@@ -182,8 +229,26 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
       }
       S->units[i].kind = k;
     }
+    if (S->deliver) {   // every unit's result buffer and its size, for the waves (address 0: the output stays on the device)
+      std::vector<uint64_t> ptrs(size_t(S->n) * 2, 0);
+      for (uint32_t i = 0; i < S->n; i++) {
+        ptrs[2 * size_t(i)] = uint64_t(reinterpret_cast<uintptr_t>(S->s[i].hbuf));
+        ptrs[2 * size_t(i) + 1] = S->s[i].hcap;
+      }
+      if (!ensure_progress(ctx) || !upload_host_ptrs(ctx, ptrs, work_stream(ctx))) return false;
+      ctx->stream_span = 0x80000000u;   // (one span: nobody waits on the counters, a turn's bytes go out when the turn ends)
+      ctx->stream_spans = 1;
+      ctx->stream_host = nullptr;
+      ctx->stream_ptrs = static_cast<const uint64_t*>(ctx->hostptrs.p);
+      ctx->stream_in_host = false;
+      ctx->stream_feed = true;
+    }
     const int rc = milzma_decode_units_impl(ctx, S->units.data(), S->n, ctx->in.p, S->out.p, S->res.data(), work_stream(ctx),
                                             MILZMA_DECODE_RESUME | MILZMA_DECODE_FEED);
+    ctx->stream_span = ctx->stream_spans = 0;
+    ctx->stream_ptrs = nullptr;
+    ctx->stream_feed = false;
+    trace_mark(ctx, "streams: launch done");
     for (uint32_t i = 0; i < S->n; i++) S->units[i].kind &= 0x0Fu;
     if (rc != MILZMA_OK) return false;
     std::vector<uint32_t> again;
@@ -192,7 +257,19 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
       One& o = S->s[i];
       const milzma_result& r = S->res[i];
       const uint64_t took = std::min<uint64_t>(r.in_consumed, S->units[i].in_len);
-      o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(took));
+      if (o.ext) {   // what the decoder has not used -- of the view (in the upload buffer) and behind it -- is kept from here on
+        const uint8_t* view = static_cast<const uint8_t*>(ctx->pin_in.p) + S->units[i].in_off;
+        const size_t in_view = size_t(S->units[i].in_len), own = o.pending.size();
+        std::vector<uint8_t> rest(view + took, view + in_view);
+        if (own > in_view) rest.insert(rest.end(), o.pending.begin() + ptrdiff_t(in_view), o.pending.end());
+        const size_t ext_used = in_view > own ? in_view - own : 0;
+        rest.insert(rest.end(), o.ext + ext_used, o.ext + o.ext_len);
+        o.pending.swap(rest);
+        o.ext = nullptr;
+        o.ext_len = 0;
+      } else {
+        o.pending.erase(o.pending.begin(), o.pending.begin() + ptrdiff_t(took));
+      }
       o.consumed += took;
       if (o.view) o.view -= size_t(took);   // (0 only with everything taken: nothing of the view is left for another round)
       if (parked(r) && r.status == MILZMA_ST_OUT_FULL) {   // more room: what its progress predicts for the bytes at hand, at least 2.5 x
@@ -207,6 +284,7 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
     }
     if (!want.empty() && !regrow(S, want)) return false;
     active.swap(again);
+    trace_mark(ctx, "streams: round done");
   }
   return true;
 }
@@ -256,6 +334,9 @@ MILZMA_HIDDEN int milzma_streams_open_impl(milzma_ctx* ctx, uint32_t kind, uint3
   if (hipSetDevice(own->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
     while (lclp > 4 && (size_t(1536) << lclp) * std::max<uint32_t>(n, 1) > free_b / 4) lclp--;
   own->slab_min_lclp = lclp;
+  // Large batches: the waves deliver.  (A small batch's launches are over before a PCIe store has crossed the link; its few copies at
+  // finish cost nothing.  MILZMA_PINNED_OUT=0 turns page-locked result buffers off altogether.)
+  S->deliver = n >= 64 && pinned_results_wanted();
   *out = S;
   return MILZMA_OK;
 }
@@ -266,6 +347,11 @@ static bool to_side(milzma_streams* S, uint32_t i, size_t before, int32_t* st) {
   milzma_streams* side = nullptr;
   if (milzma_streams_open_impl(S->ctx, S->kind | (S->as_reader ? MILZMA_STREAMS_AS_READER : 0u), 1, &o.opt, &side) != MILZMA_OK) return false;
   const uint32_t zero = 0;
+  if (o.ext) {   // (everything in one piece for the batch of its own)
+    o.pending.insert(o.pending.end(), o.ext, o.ext + o.ext_len);
+    o.ext = nullptr;
+    o.ext_len = 0;
+  }
   const void* data = o.pending.data();
   const size_t len = o.pending.size();
   int32_t s1 = MILZMA_OK;
@@ -306,8 +392,8 @@ static bool run_cursors(milzma_streams* S, const std::vector<WriteCursor>& cur, 
   std::vector<uint8_t> partial_path(cur.size());
   for (size_t c = 0; c < cur.size(); c++) {
     One& o = S->s[cur[c].i];
-    total[c] = cur[c].view ? std::min(cur[c].view, o.pending.size()) : o.pending.size();
-    behind[c] = o.pending.size() - total[c];
+    total[c] = cur[c].view ? std::min(cur[c].view, o.held()) : o.held();
+    behind[c] = o.held() - total[c];
     begin[c] = total[c] - std::min(cur[c].data, total[c]);
     partial_path[c] = S->partial() && o.started && begin[c] > 0;   // (a unit that starts holds the five start bytes, not a symbol's)
     o.view = cur[c].view;
@@ -366,6 +452,25 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
     }
     seen[idx[j]] = 1;
   }
+  struct DropExt {   // (whatever way the call ends: no stream keeps a pointer into the caller's buffers)
+    milzma_streams* S;
+    uint32_t k;
+    const uint32_t* idx;
+    ~DropExt() {
+      for (uint32_t j = 0; j < k; j++) {
+        One& o = S->s[idx[j]];
+        if (o.ext) {   // (not taken over by a round: an infrastructure failure on the way -- the batch is closed by its owner; keep the bytes anyway)
+          try {
+            o.pending.insert(o.pending.end(), o.ext, o.ext + o.ext_len);
+          } catch (const std::exception&) {
+          }
+          o.ext = nullptr;
+          o.ext_len = 0;
+        }
+      }
+    }
+  } drop_ext{S, k, idx};
+  trace_mark(ctx, "streams: write begins");
   std::vector<int32_t> st(k, MILZMA_OK);
   std::vector<uint64_t> refused(k, 0);   // bytes of the write the stream does not take (> 0: ErrorKind::WriteZero)
   std::vector<size_t> before(k, 0);      // bytes the stream held when the call began
@@ -375,6 +480,26 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
   parallel_for(k, [&](size_t j) {
     One& o = S->s[idx[j]];
     before[j] = o.pending.size();
+    if (len[j] && o.st == One::DATA && o.started && o.in_tmp == 0) {   // a running stream: its data stay where they are until the upload
+      o.ext = static_cast<const uint8_t*>(data[j]);
+      o.ext_len = len[j];
+      return;
+    }
+    if (len[j] >= 64 && o.st == One::HEADER && o.pending.empty()) {
+      // a stream's first bytes, header and all in one piece: only what the header (<= 13 bytes) and the range coder's start (5) can take is
+      // kept here, the rest stays with the caller until the upload
+      const size_t head = S->kind == MILZMA_KIND_LZMA2 ? 0 : 18;
+      const uint8_t* p = static_cast<const uint8_t*>(data[j]);
+      try {
+        o.pending.assign(p, p + head);
+      } catch (const std::exception&) {
+        no_memory.store(1);
+        return;
+      }
+      o.ext = p + head;
+      o.ext_len = len[j] - head;
+      return;
+    }
     if (len[j] && (o.st == One::HEADER || o.st == One::DATA)) {   // (a SIDE stream's bytes are passed on below)
       const uint8_t* p = static_cast<const uint8_t*>(data[j]);
       try {   // (an exception must not leave a host thread)
@@ -443,7 +568,7 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
           u.kind = MILZMA_KIND_LZMA2;
           S->units[i] = u;
           o.st = One::DATA;
-          then.push_back({j, i, o.pending.size(), 0});
+          then.push_back({j, i, o.held(), 0});
           break;
         }
         // The crate reads the header from the written data itself -- or, once an earlier write has left bytes in Stream.tmp, from THAT
@@ -477,7 +602,7 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
         S->units[i] = u;
         o.st = One::DATA;
         const size_t in_tmp = via_tmp ? shown - hl - 5 : 0;      // bytes Stream.tmp keeps behind the header and the five start bytes
-        const size_t rest = o.pending.size() - 5 - in_tmp;       // what write_all hands to the next write() call
+        const size_t rest = o.held() - 5 - in_tmp;               // what write_all hands to the next write() call
         if (in_tmp == 0) {
           then.push_back({j, i, rest, 0});
         } else if (rest == 0) {
@@ -522,6 +647,7 @@ MILZMA_HIDDEN int milzma_streams_write_impl(milzma_streams* S, uint32_t k, const
   }
   if (status)
     for (uint32_t j = 0; j < k; j++) status[j] = st[j];
+  trace_mark(ctx, "streams: write done");
   return MILZMA_OK;
 }
 
@@ -545,11 +671,12 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     return MILZMA_INFRA_ERROR;
   }
   int worst = MILZMA_OK;
-  // Every stream's bytes go from its slice straight into its result buffer: page-locked buffers from the pool when a batch is large
-  // (the copies then run at link speed and nothing is copied twice), all copies queued on the work stream, one wait.
+  // The streams' result buffers have been filled by the decoding waves, turn by turn, under the kernels of the write calls
+  // (milzma_streams::deliver): nothing is left to copy.  Where that is off (small batches, no page-locked memory): every stream's bytes go
+  // from its slice into a buffer from the pool, all copies queued on the work stream, one wait.
   const bool pinned = S->n >= 64 && pinned_results_wanted();
   std::vector<milzma_result> fin(S->n);
-  std::vector<uint8_t> has(S->n, 0);
+  std::vector<uint8_t> has(S->n, 0), delivered(S->n, 0);
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) {
     for (uint32_t i = 0; i < S->n; i++) infra(ctx, &outs[i]);
     return MILZMA_INFRA_ERROR;
@@ -583,7 +710,14 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
       r.out_flushed = r.out_len;
     }
     const size_t visible = size_t(std::min<uint64_t>(r.out_flushed, S->units[i].out_cap));
-    out->data = out_alloc(visible, pinned && visible >= 4096);
+    if (S->deliver && o.hbuf && visible <= o.hcap) {   // the waves have filled it while they decoded: handed over as it is
+      out->data = o.hbuf;
+      o.hbuf = nullptr;
+      o.hcap = 0;
+      delivered[i] = 1;
+    } else {
+      out->data = out_alloc(visible, pinned && visible >= 4096);
+    }
     if (!out->data) {
       out_fail(out, MILZMA_INFRA_ERROR, "out of memory");
       return;
@@ -608,7 +742,7 @@ MILZMA_HIDDEN int milzma_streams_finish_impl(milzma_streams* S, milzma_output* o
     }
   bool copies_ok = true;
   for (uint32_t i = 0; i < S->n && copies_ok; i++)
-    if (has[i] && outs[i].len)
+    if (has[i] && outs[i].len && !delivered[i])
       copies_ok = hip_ok(ctx, hipMemcpyAsync(outs[i].data, static_cast<const uint8_t*>(S->out.p) + S->units[i].out_off, outs[i].len, hipMemcpyDeviceToHost,
                                              work_stream(ctx)),
                          "D2H output");
@@ -675,11 +809,16 @@ MILZMA_HIDDEN int milzma_streams_output_impl(milzma_streams* S, uint32_t stream,
 
 MILZMA_HIDDEN void milzma_streams_close_impl(milzma_streams* S) {
   if (!S) return;
-  for (One& o : S->s)
+  for (One& o : S->s) {
     if (o.side) {
       milzma_streams_close_impl(o.side);
       o.side = nullptr;
     }
+    if (o.hbuf) {
+      milzma_free(o.hbuf);
+      o.hbuf = nullptr;
+    }
+  }
   if (S->ctx) {
     (void)hipSetDevice(S->ctx->device);
     dev_release(S->out);

@@ -19,10 +19,16 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def forced():
+    """MILZMA_DIST_FORCE=1: the process group is initialised -- and scatter / gather go through it -- at world size 1 too: RCCL's first
+    contact happens on the one GPU a test box has, not on the first 8-GPU node (tests/test_gpu_production_paths.py)."""
+    return os.environ.get("MILZMA_DIST_FORCE") == "1"
+
+
 def init(backend=None):
-    """Initialise the default process group when WORLD_SIZE > 1. Returns (rank, local_rank, world)."""
+    """Initialise the default process group when WORLD_SIZE > 1 (or forced()). Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:  # MILZMA_DIST_BACKEND=gloo: dry runs of the multi-rank path on a box with fewer GPUs than ranks
@@ -90,9 +96,13 @@ def device_identity(index):
     import zlib
     props = torch.cuda.get_device_properties(index)
     ident = getattr(props, "uuid", None)
-    where = "%s/%s/%s/%s" % (socket.gethostname(), getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", index),
-                             getattr(props, "pci_device_id", 0))
-    return zlib.crc32((where + "/" + str(ident)).encode()) | (1 << 40)
+    bus = getattr(props, "pci_bus_id", None)
+    if ident is None and bus is None:
+        # No physical identity to be had from this torch build (ranks launched with their own HIP_VISIBLE_DEVICES all see index 0: the
+        # index says nothing): 0 = unknown -- the caller must not refuse a run over it
+        return 0
+    where = "%s/%s/%s/%s" % (socket.gethostname(), getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))
+    return zlib.crc32((where + "/" + (str(ident) if ident is not None else "")).encode()) | (1 << 40)
 
 
 def scatter_inputs(chunks, device):
@@ -100,7 +110,7 @@ def scatter_inputs(chunks, device):
     its own chunk on `device`.  Lengths travel first, then the payloads as point-to-point sends
     (xGMI is point-to-point: one send per peer is the natural pattern)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    if world == 1:
+    if world == 1 and not (forced() and dist.is_initialized()):
         return chunks[0].to(device)
     # gloo moves host tensors only (dry runs: several ranks on a box with fewer GPUs): stage through the host there
     wire = torch.device("cpu") if dist.get_backend() == "gloo" else device
@@ -122,7 +132,7 @@ def scatter_inputs(chunks, device):
 def gather_outputs(local_out, device):
     """All ranks contribute a uint8 tensor (lengths may differ); rank 0 receives the list (on `device`)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    if world == 1:
+    if world == 1 and not (forced() and dist.is_initialized()):
         return [local_out]
     wire = torch.device("cpu") if dist.get_backend() == "gloo" else device
     n = torch.tensor([local_out.numel()], dtype=torch.int64, device=wire)

@@ -166,3 +166,30 @@ def test_differential_fuzz_of_the_batch_calls(ctx, mode, monkeypatch):
         assert (d.kind, d.msg, d.data) == (refs[i].kind, refs[i].msg, refs[i].out), ("xz fuzz", i, d.msg, refs[i].msg)
     if mode != "default":
         assert streamed_seen == 3, "only %d of the three batches took the streamed launch" % streamed_seen
+
+
+def test_rccl_first_contact_at_world_size_one():
+    """no multi-GPU node has been available to any round, so RCCL itself had never run.  bench.py's rank path -- the process
+    group over the real `nccl` backend (= RCCL), barriers, the MAX / SUM all-reduces and the all-gather on DEVICE tensors, the scatter of the
+    compressed input from rank 0, the gather of the decoded output and its CRC check -- at world size 1 on the one GPU there is
+    (MILZMA_DIST_FORCE=1): the first contact with an 8-GPU node is then not also the first contact with RCCL."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MILZMA_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MILZMA_KERNEL", "MILZMA_SPILL", "MILZMA_SLICE", "MILZMA_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--scatter", "--steps", "2", "--warmup", "1", "--streams", "96",
+                        "--size", "65536", "--distinct", "24", "--no-cpu-baseline", "--other-configs", "none"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])   # (RCCL prints its own lines around it)
+    assert line["ranks"]["backend"].startswith("nccl") and line["ranks"]["world"] == 1, line["ranks"]
+    sg = line["scatter_gather"]
+    assert sg["gathered_units_bad"] == 0 and line["value"] > 0, sg
+    assert line["config"].get("verified_streams_per_gpu", line.get("verified_streams_per_gpu", 0)) == 96, line

@@ -208,8 +208,10 @@ def test_asm_loops_sit_in_the_code_object_untouched():
     # 4096 streams through the sliced kernel take the ordinary kernel's time, parked at every quantum +0.5 % (profiles/r05_sliced_and_streamed.txt).
     for name, m in rep["kernels"].items():
         if "sliced" in name:
-            assert m["private_segment_fixed_size"] <= 1600 and m["vgpr_spill_count"] <= 650, (name, m)
-            assert m["scratch_instructions_outside_the_loops"] <= 1000, (name, m)
+            # (round 6: measured 557 spills / 1452 B / 944 scratch instructions -- + 10 %.  The figure wobbles by +- 50 with any edit of the C++ around
+            #  the loop: 443 at the end of round 5, 511 .. 557 over this round's edits, the smallest source the largest count)
+            assert m["private_segment_fixed_size"] <= 1600 and m["vgpr_spill_count"] <= 615, (name, m)
+            assert m["scratch_instructions_outside_the_loops"] <= 1040, (name, m)
         else:
             assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
             assert m["scratch_instructions_outside_the_loops"] <= 8, (name, m)

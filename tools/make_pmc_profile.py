@@ -74,11 +74,24 @@ def main():
                                         ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_SCA",
                                          "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_MISC")
                                         if k in counters}
+    # the issue pipes as the counters see them (the priced model of bench.py's roofline_issue beside it):
+    #   cycles of the launch = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), 1024 SIMDs, 256 CUs
+    #   vector pipe: SQ_ACTIVE_INST_VALU counts issue quads (4 cycles) summed over all SIMDs
+    #   scalar pipe: SQ_INST_CYCLES_SALU = cycles the CU's scalar unit spent on scalar ALU instructions, summed over all CUs
+    if all(k in counters for k in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INST_CYCLES_SALU", "SQ_INSTS_BRANCH")):
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+        derived["pipe_busy_from_counters"] = {
+            "launch_cycles": cyc,
+            "valu_busy": round(counters["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 4),
+            "salu_busy": round(counters["SQ_INST_CYCLES_SALU"] / (256.0 * cyc), 4),
+            "branch_per_cycle_per_cu": round(counters["SQ_INSTS_BRANCH"] / (256.0 * cyc), 4),
+            "how": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles); salu_busy = SQ_INST_CYCLES_SALU / (256 CUs x cycles); "
+                   "branch_per_cycle_per_cu = SQ_INSTS_BRANCH / (256 x cycles); cycles = GRBM_GUI_ACTIVE / 8 XCDs"}
     with open(out, "w") as f:
         json.dump({"kernel_source_sha256": bench.kernel_source_hash(), "config": config,
                    "command": "rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- python bench.py %s "
                               "--steps 1 --warmup 0 --no-cpu-baseline --no-verify --other-configs none "
-                              "(experiments/gpu_calls/r5_evidence.sh)" % ("--unknown-size" if first_only else "--config " + config),
+                              "(experiments/gpu_calls/r6_evidence.sh)" % ("--unknown-size" if first_only else "--config " + config),
                    "dispatches_per_pass": passes, "kernel_ms_under_pmc": round(sum(dur) / max(1, len(dur)), 2),
                    "counters_per_launch": counters, "derived": derived}, f, indent=1)
         f.write("\n")
