@@ -30,15 +30,23 @@ def _hdr(comp):
 @pytest.fixture(scope="module")
 def loops():
     m = {True: asmprog.AsmLoop(lp0=True), False: asmprog.AsmLoop(lp0=False), "lc4": asmprog.AsmLoop(lp0=False, pb4=True, hbm=True),
+         "hb0": asmprog.AsmLoop(lp0=True, pb4=False, hbm=True),   # (round 6: lc >= 4 with lp == 0 and pb <= 2)
          "pb4": asmprog.AsmLoop(lp0=False, pb4=True)}     # ("lc4": lc + lp = 4 runs in the HBM variant since round 4)
     yield m
     for a in set(m.values()):
         a.close()
 
 
+def _pick(loops, lc, lp, pb):
+    """the loop variant AsmDecoder::process runs for this property set"""
+    if lc + lp >= 4:
+        return loops["hb0" if lp == 0 and pb <= 2 else "lc4"]
+    return loops["pb4" if pb > 2 else lp == 0]
+
+
 def _check(loops, comp, plain):
     lc, lp, pb, ds, us = _hdr(comp)
-    r = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0].decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
+    r = _pick(loops, lc, lp, pb).decode_raw(comp[13:], lc, lp, pb, ds, us, out_cap=max(len(plain), 1))
     ref = orc.lzma_decompress(comp)
     assert ref.out == plain
     assert r["status"] == "OK" and r["out"] == plain
@@ -116,7 +124,7 @@ def test_emulated_lc4_through_the_row_caches(loops, lc, lp, pb):
     filt = [{"id": lzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 16}]
     comp = lzma.compress(plain, format=lzma.FORMAT_ALONE, filters=filt)
     _check(loops, comp, plain)
-    emu = loops["lc4"]
+    emu = _pick(loops, lc, lp, pb)
     emu.reset_counts()
     emu.decode_raw(comp[13:], lc, lp, pb, 1 << 16, None, out_cap=len(plain) + 8)
     c, _ = emu.counts()
@@ -133,7 +141,7 @@ def test_emulated_reader_at_every_cut(loops, lc, lp, pb):
     """the loop's reader (end-aligned last window, "reader at EOF" state) against the oracle for EVERY prefix of short streams: known
     size, unknown size with marker, unknown size without marker (finished only if the reader is at EOF with code == 0), lengths
     around the 64-byte window: status, bytes decoded and reader position"""
-    emu = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    emu = _pick(loops, lc, lp, pb)
     plain = W.make_plain("text", 700, seed=5) + bytes(range(200))
     for known, marker in ((True, False), (False, True)):
         comp = W.compress_alone(plain, dict_size=4096, known_size=known, lc=lc, lp=lp, pb=pb)
@@ -169,7 +177,7 @@ def test_emulated_loop_yields_at_quanta(loops, lc, lp, pb):
     kernel's resume (reader re-seeked, tables rebuilt).  Whatever the quantum -- every symbol, odd sizes, larger than the stream --
     status, bytes and reader position are those of the uninterrupted run, for good, truncated and size-mismatched streams and at
     the output limit."""
-    emu = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    emu = _pick(loops, lc, lp, pb)
     rng = random.Random(lc * 100 + lp * 10 + pb)
     cases = []
     for kind, n in (("text", 6000), ("random", 1500), ("repeat", 9000), ("zeros", 3000)):
@@ -203,7 +211,7 @@ def test_emulated_loop_fed_in_views(loops, lc, lp, pb):
     the middle of a symbol --, is re-entered on the longer view, and runs the whole payload last without the bit: bytes, verdict and reader
     position are the oracle's, for good streams of known and unknown size and for a truncated one."""
     import gen_fast_loop as G
-    loop = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    loop = _pick(loops, lc, lp, pb)
     rng = random.Random(lc * 100 + lp * 10 + pb)
     for kind, known, size in (("text", True, 90000), ("text", False, 40000), ("random", True, 9000), ("repeat", False, 50000)):
         plain = W.make_plain(kind, size, seed=77 + size)
@@ -231,7 +239,7 @@ def test_emulated_loop_goes_on_behind_an_end_marker(loops, lc, lp, pb):
     """The crate's Partial mode at an end marker (lzma.rs:493-495, :507-509; MILZMA_KIND_PARTIAL): the loop of a write merely leaves at
     `Finished`, and bytes written later are decoded on from the marker's state -- rep[0] = 0xFFFF_FFFF, the state after a match.  The
     loop, re-entered from that state on a longer view, against the oracle's Stream fed the same two pieces."""
-    loop = loops["lc4" if lc + lp == 4 else "pb4" if pb > 2 else lp == 0]
+    loop = _pick(loops, lc, lp, pb)
     rng = random.Random(4000 + lc * 100 + lp * 10 + pb)
     plain = W.make_plain("text", 6000, seed=5)
     head = W.compress_alone(plain, dict_size=1 << 16, lc=lc, lp=lp, pb=pb, known_size=False)
@@ -276,10 +284,12 @@ def test_emulated_hbm_variant_lclp_above_four():
     marker-terminated, truncated, with a quantum that parks the walk every 2500 bytes -- against the oracle."""
     import random
     import lzma_enc as E
-    emu = asmprog.AsmLoop(lp0=False, pb4=True, hbm=True)
+    emu_hbm = asmprog.AsmLoop(lp0=False, pb4=True, hbm=True)
+    emu_hb0 = asmprog.AsmLoop(lp0=True, pb4=False, hbm=True)   # round 6: the same slab behind the LP0 variant's bookkeeping (lp == 0, pb <= 2)
     try:
         rnd = random.Random(3)
-        for (lc, lp, pb) in [(8, 0, 2), (4, 4, 0), (5, 2, 4), (8, 4, 4), (3, 0, 2), (4, 0, 2), (0, 0, 0)]:
+        for (lc, lp, pb, emu) in [(8, 0, 2, emu_hbm), (4, 4, 0, emu_hbm), (5, 2, 4, emu_hbm), (8, 4, 4, emu_hbm), (3, 0, 2, emu_hbm), (4, 0, 2, emu_hbm),
+                                  (0, 0, 0, emu_hbm), (8, 0, 2, emu_hb0), (4, 0, 2, emu_hb0), (6, 0, 0, emu_hb0), (5, 0, 1, emu_hb0), (3, 0, 2, emu_hb0)]:
             size = 90_000
             plain = (W.make_plain("text", size - 30000, seed=lc * 100 + lp * 10 + pb) + rnd.randbytes(15000) + bytes(range(256)) * 58 + b"x" * 152)[:size]
             for known in (True, False):
@@ -299,7 +309,8 @@ def test_emulated_hbm_variant_lclp_above_four():
                 assert r["status"] == "INPUT_EOF" and r["in_consumed"] + 13 == ref.in_consumed
                 assert r["out"][:len(ref.out)] == ref.out
     finally:
-        emu.close()
+        emu_hbm.close()
+        emu_hb0.close()
 
 
 _KNOB_SCRIPT = r"""

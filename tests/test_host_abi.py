@@ -143,7 +143,7 @@ def test_asm_loop_wait_states():
     branches end a run: a taken branch is more than two wait states)."""
     inc = open(os.path.join(ROOT, "lzma_rs_amd", "csrc", "fast_loop_asm.inc")).read()
     runs = re.findall(r'#define MILZMA_FAST_LOOP_TEXT_\w+ \\\n((?:  ".*" \\\n)+)', inc)
-    assert len(runs) in (4, 5)  # LP0, GEN, PB4, HBM (+ LP0V in the MIXV tuning build)
+    assert len(runs) in (5, 6)  # LP0, GEN, PB4, HBM, HB0 (+ LP0V in the MIXV tuning build)
     checked = 0
     for text in runs:
         lines = [m for m in re.findall(r'"([^"]*)\\n\\t"', text)]
@@ -194,24 +194,24 @@ def test_rust_shim_declares_the_header_abi():
 
 
 def test_asm_loops_sit_in_the_code_object_untouched():
-    """Every instance of the generated symbol loop (LP0 / GEN / PB4 / HBM, in the ordinary and in the time-sliced kernel: eight in all) is found in the built code object instruction for instruction -- so nothing of the compiler's, in
+    """Every instance of the generated symbol loop (LP0 / GEN / PB4 / HBM / HB0, in the ordinary and in the time-sliced kernel: ten in all) is found in the built code object instruction for instruction -- so nothing of the compiler's, in
     particular none of the scratch_ spill traffic the time-sliced instantiations carry around the loop, sits between a loop's first
     and last instruction.  The ordinary kernels must stay (nearly) scratch-free altogether; the sliced ones are bounded."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_code_object as C
     rep, problems = C.check(os.path.join(ROOT, "lzma_rs_amd", "libmilzma.so"))
     assert not problems, problems
-    assert len(rep["loops"]) == 8
+    assert len(rep["loops"]) == 10
     # A spill budget per kernel, so that the figures cannot double unnoticed again (VERDICT r4 weak 3: 373 -> 588 VGPR spills in one round).
     # The time-sliced kernel's spills sit around its park / unpark code (21.5 KB of state per unit: parking IS a round trip through
     # memory) and run once per TURN -- about 900 scratch instructions against the ~7 million instructions of a 128 KiB turn; measured:
     # 4096 streams through the sliced kernel take the ordinary kernel's time, parked at every quantum +0.5 % (profiles/r05_sliced_and_streamed.txt).
     for name, m in rep["kernels"].items():
         if "sliced" in name:
-            # (round 6: measured 557 spills / 1452 B / 944 scratch instructions -- + 10 %.  The figure wobbles by +- 50 with any edit of the C++ around
-            #  the loop: 443 at the end of round 5, 511 .. 557 over this round's edits, the smallest source the largest count)
-            assert m["private_segment_fixed_size"] <= 1600 and m["vgpr_spill_count"] <= 615, (name, m)
-            assert m["scratch_instructions_outside_the_loops"] <= 1040, (name, m)
+            # (round 6: measured 592 spills / 1432 B / 1028 scratch instructions -- + 10 %.  The figure wobbles by +- 50 with any edit of the C++ around
+            #  the loop: 443 at the end of round 5, 511 .. 592 over this round's edits -- removing code raised it as often as adding did)
+            assert m["private_segment_fixed_size"] <= 1580 and m["vgpr_spill_count"] <= 650, (name, m)
+            assert m["scratch_instructions_outside_the_loops"] <= 1130, (name, m)
         else:
             assert m["private_segment_fixed_size"] <= 64 and m["vgpr_spill_count"] <= 8, (name, m)
             assert m["scratch_instructions_outside_the_loops"] <= 8, (name, m)

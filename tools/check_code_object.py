@@ -69,8 +69,8 @@ def disassemble(co):
 def generated_variants():
     import gen_fast_loop as G
     out = {}
-    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)):
-        g = G.Gen(lp0, pb4, hbm=(name == "HBM"))
+    for name, lp0, pb4 in (("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True), ("HB0", True, False)):
+        g = G.Gen(lp0, pb4, hbm=(name in ("HBM", "HB0")))
         g.build()
         lines = g.main + g.cold + g.cold2 + g.stubs
         g.cur = lines
@@ -93,7 +93,7 @@ def check(so):
     for fname, mn in funcs.items():
         if "decode_fast_asm" not in fname:
             continue
-        want = ["LP0", "GEN", "PB4", "HBM"]
+        want = ["LP0", "GEN", "PB4", "HBM", "HB0"]
         anchors = [i for i, x in enumerate(mn) if x == "s_getpc_b64"]
         found = []
         for a in anchors:

@@ -5,7 +5,9 @@ register allocator / block placement (rocprof on a C++ loop: 45 % of issued inst
 other compiler glue).  Variants, all with the same register numbering (one kernel, 128 VGPRs, four waves per SIMD): LP0 (lp == 0,
 pb <= 2: the headline), GEN (any lp, pb <= 2), PB4 (pb 3 / 4) -- these three for lc + lp <= 3 -- and HBM (lc + lp >= 4, any pb: the
 literal rows in a slab in memory behind eight cached rows; round 4 -- it replaced the LC4 variant and its 152-VGPR kernel, which ran
-lc + lp = 4 at three waves per SIMD: 11.9 GB/s against 15.1 now, profiles/r04_lclp_classes.txt).
+lc + lp = 4 at three waves per SIMD: 11.9 GB/s against 15.1 now, profiles/r04_lclp_classes.txt) -- and, round 6, HB0: the same slab and
+row caches for lc >= 4 with lp == 0 and pb <= 2 (lc4/lp0/pb2, the one such class liblzma's presets reach) without the GEN / PB4
+variants' dearer bookkeeping: 56.5 instead of 58.2 instructions per byte on lc4 text (the LP0 loop on lc3: 55.2).
 
 What the loop does is DecoderState::process_mode(Finish) (src/decode/lzma.rs:435-524) with
 decode_literal (526-561), decode_distance (563-592), LenDecoder::decode (rangecoder.rs:256-269),
@@ -315,7 +317,8 @@ class Gen:
         # slot holds another (one load + wait: the price of a miss), the evicted one goes back with a store nobody waits for.  The
         # row the literal walk is on (u0..u3) owns its slot.  Needs LITSPLIT's layout (gpr index = slot).
         self.hbm = hbm
-        assert not hbm or (pb4 and not lp0 and LITSPLIT)
+        assert not hbm or LITSPLIT
+        assert not hbm or (pb4 and not lp0) or (lp0 and not pb4)   # HBM: any lp / pb; HB0 (round 6): lp == 0, pb <= 2
         self.lp0 = lp0  # generate for lp == 0 (literal row = prev >> (8 - lc))
         # pb4: up to 16 position states.  is_match / is_rep0long [state * 16 + pos_state] span three registers (lanes
         # 0..63 / 64..127 / 128..191 by the index's bits 6-7), len low / mid [pos_state] two (pos_state bit 3; roots at lanes
@@ -923,7 +926,7 @@ class Gen:
         e, L = self.e, self.L
         e("s_getpc_b64 " + JBASE)
         self.lab("base")
-        vid = 4 if self.hbm else 3 if self.pb4 else 1 if self.lp0 else 2  # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
+        vid = (5 if self.lp0 else 4) if self.hbm else 3 if self.pb4 else 1 if self.lp0 else 2  # (tbl_b holds offsets into THIS variant of the loop: an LZMA2
         e("s_cmp_eq_u32 {tbl_ready}, %d" % vid)             #  unit may change lp, and with it the variant, between chunks)
         e("s_cbranch_scc1 " + L("tbl_done"))
         bs = "(" + L("direct_done") + "-" + L("direct_chain") + ")/26"
@@ -1301,8 +1304,6 @@ class Gen:
         e, L = self.e, self.L
         e("s_and_b32 {t0}, {row}, 7")
         e("v_lshl_add_u32 {VA}, {t0}, 10, {VL16}")
-        e("s_mul_i32 {t2}, {row}, 0x600")
-        e("s_add_u32 {t2}, {t2}, 0x200")
         e("s_nop 1")
         e("v_readlane_b32 {t1}, {vtagm}, {t0}")
         e("s_cmp_lg_u32 {t1}, {row}")
@@ -1321,6 +1322,8 @@ class Gen:
             e("s_waitcnt lgkmcnt(0)")
             e("buffer_store_dwordx4 " + MROW + ", {VT2}, {lit_rsrc}, 0 offen")
             self.lab("Omrow_get")
+            e("s_mul_i32 {t2}, {row}, 0x600")                   # (the row's place in the slab: only a miss needs it)
+            e("s_add_u32 {t2}, {t2}, 0x200")
             e("v_lshl_add_u32 {VT2}, {v_lane}, 4, {t2}")
             e("buffer_load_dwordx4 " + MROW + ", {VT2}, {lit_rsrc}, 0 offen")
             e("s_mov_b32 m0, {t0}")
@@ -2064,13 +2067,14 @@ MIXV = os.environ.get("MILZMA_GEN_MIXV", "0") == "1"
 def main():
     global NORM_S, VB2_INLINE
     texts, clobbers, fixeds = {}, {}, {}
-    variants = [("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True)] + ([("LP0V", True, False)] if MIXV else [])
+    variants = ([("LP0", True, False), ("GEN", False, False), ("PB4", False, True), ("HBM", False, True), ("HB0", True, False)] +
+                ([("LP0V", True, False)] if MIXV else []))
     for name, lp0, pb4 in variants:
         saved = (NORM_S, VB2_INLINE)
         if name == "LP0V":
             NORM_S = NORM_S - {"tree"}
             VB2_INLINE = DISP2 and not NORM_S >= {"tree", "single", "lit", "direct"}
-        g = Gen(lp0, pb4, hbm=(name == "HBM"))
+        g = Gen(lp0, pb4, hbm=(name in ("HBM", "HB0")))
         g.build()
         NORM_S, VB2_INLINE = saved
         lines = g.main + g.cold + g.cold2 + g.stubs
@@ -2084,7 +2088,8 @@ def main():
     out.append("// GENERATED by tools/gen_fast_loop.py -- do not edit; edit the generator and re-run it.")
     out.append("// The symbol loop of decode_fast_asm_kernel as one inline-asm statement (see the generator's docstring):")
     out.append("// MILZMA_FAST_LOOP_TEXT_LP0 for lp == 0, _GEN for any lp, _PB4 for pb 3 / 4 (any lp) -- lc + lp <= 3 --, _HBM for lc + lp >= 4 (any pb:")
-    out.append("// the literal rows in a slab in memory); one operand list for all of them.")
+    out.append("// the literal rows in a slab in memory), _HB0 for lc >= 4 with lp == 0 and pb <= 2 (the same slab behind the LP0 variant's cheaper")
+    out.append("// bookkeeping); one operand list for all of them.")
     out.append("// clang-format off")
     for k, v in EXIT.items():
         out.append("#define MILZMA_LOOP_EXIT_%s %du" % (k, v))
@@ -2103,6 +2108,7 @@ def main():
     assert clobbers["LP0"] == clobbers["GEN"] and fixeds["LP0"] == fixeds["GEN"]
     assert clobbers["LP0"] == clobbers["PB4"] and fixeds["LP0"] == fixeds["PB4"]
     assert clobbers["LP0"] == clobbers["HBM"] and fixeds["LP0"] == fixeds["HBM"]
+    assert clobbers["LP0"] == clobbers["HB0"] and fixeds["LP0"] == fixeds["HB0"]
 
     def common(vnames):
         return ([('"+{%s}"(d.%s)' % (FIXED_OPERANDS[n], n)) if n in FIXED_OPERANDS else ('[%s] "+s"(d.%s)' % (n, n)) for n in OPS_INOUT_S] +
