@@ -547,7 +547,9 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
         cap = uint32_t(entries);
         if (sliced && want_stream) {
           if (ensure_progress(ctx)) {
-            memset(ctx->progress, 0, milzma_ctx::kMaxSpans * sizeof(uint32_t));
+            // (stream_feed: nobody reads the counters, and an earlier launch of this very call may still be adding to them -- found by
+            //  ThreadSanitizer on the stand-in kernels)
+            if (!ctx->stream_feed) memset(ctx->progress, 0, milzma_ctx::kMaxSpans * sizeof(uint32_t));
             ctx->stream_active = true;
           }
         }

@@ -445,11 +445,14 @@ bool raw_feed_loop(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, const st
 // 3e. the push-mode API (milzma_streams_*: lzma_rs::decompress::Stream for a batch): good .lzma files written in four pieces each, on
 // schedules of their own -- some streams join calls later (MILZMA_KIND_START inside a resuming call), all of them sit calls out
 // (MILZMA_KIND_HOLD) --, one with a bad header, one never completed; finish against the one-shot oracle.
-bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool) {
+// copies > 1: the same files several times over -- a batch of >= 64 streams, whose result buffers are filled by the (stand-in) kernels
+// themselves while they "decode" (milzma_streams::deliver, host_stream.cpp).
+bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, size_t copies = 1) {
   std::vector<const Case*> files;
   std::vector<orc_result> want;
+  for (size_t rep = 0; rep < copies; rep++)
   for (const Case& c : lzma_pool) {
-    if (files.size() >= 14) break;
+    if (files.size() >= 14 * copies) break;
     orc_result w;
     memset(&w, 0, sizeof w);
     orc_lzma_decompress(ptr_of(c.data), c.data.size(), nullptr, &w);
@@ -493,6 +496,11 @@ bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool) {
       data.push_back(ptr_of(files[0]->data));
       len.push_back(7);
     }
+    if (call == 4) {   // the stream whose header write failed is dead: it refuses bytes (ErrorKind::WriteZero), it does not swallow them
+      idx.push_back(n - 2);
+      data.push_back(bad_header);
+      len.push_back(5);
+    }
     std::vector<int32_t> st(idx.size(), -1);
     if (milzma_streams_write(S, uint32_t(idx.size()), idx.data(), data.data(), len.data(), st.data()) != MILZMA_OK) {
       printf("INFRA streams_write, call %d: %s\n", call, milzma_streams_last_error(S));
@@ -501,9 +509,23 @@ bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool) {
     }
     for (size_t j = 0; j < idx.size(); j++) {
       const bool should_fail = idx[j] == n - 2;
-      if ((st[j] != MILZMA_OK) != should_fail || (should_fail && !strstr(milzma_streams_write_error(S, idx[j]), "must be < 225"))) {
+      const char* text = call == 4 ? "failed to write whole buffer" : "must be < 225";
+      if ((st[j] != MILZMA_OK) != should_fail || (should_fail && !strstr(milzma_streams_write_error(S, idx[j]), text)) ||
+          (!should_fail && milzma_streams_write_taken(S, idx[j]) != len[j]) || (should_fail && call == 4 && milzma_streams_write_taken(S, idx[j]) != 0)) {
         printf("MISMATCH streams_write: stream %u status %d (%s)\n", idx[j], st[j], milzma_streams_write_error(S, idx[j]));
         ok = false;
+      }
+    }
+    if (ok && call == 5) {   // Stream::get_output between writes: whole rings only, none for the dead stream
+      for (uint32_t i = 0; i < n && ok; i++) {
+        uint64_t sink = 0;
+        int32_t has = -1;
+        std::vector<uint8_t> buf(1 << 16);
+        if (milzma_streams_output(S, i, 0, buf.data(), buf.size(), &sink, &has) != MILZMA_OK || has != (i == n - 2 ? 0 : 1) ||
+            (i < files.size() && sink > want[i].out_len)) {
+          printf("MISMATCH streams_output: stream %u has %d sink %llu\n", i, has, (unsigned long long)sink);
+          ok = false;
+        }
       }
     }
   }
@@ -903,6 +925,7 @@ int main(int argc, char** argv) {
     if (ok) ok = raw_grow_loop(ctx, pool[LZMA], pool[LZMA2]);
     if (ok) ok = raw_feed_loop(ctx, pool[LZMA], pool[LZMA2]);
     if (ok) ok = streams_api(ctx, pool[LZMA]);
+    if (ok) ok = streams_api(ctx, pool[LZMA], 6);   // (>= 64 streams: the result buffers are filled by the kernels)
     // milzma_xz_plan: the Index of a good file -> one unit per block; decoded, every block's bytes where the plan put them
     for (const Case& c : pool[XZ]) {
       if (!ok) break;
