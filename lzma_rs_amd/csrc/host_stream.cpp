@@ -236,7 +236,10 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
         ptrs[2 * size_t(i) + 1] = S->s[i].hcap;
       }
       if (!ensure_progress(ctx) || !upload_host_ptrs(ctx, ptrs, work_stream(ctx))) return false;
-      ctx->stream_span = 0x80000000u;   // (one span: nobody waits on the counters, a turn's bytes go out when the turn ends)
+      // ONE span: nobody waits on the counters, a turn's bytes go out when the turn ends (the scheduler's quantum: 96 .. 192 KiB).  (Cutting
+      // the turns at staggered 64 KiB spans like the whole-file calls' streamed launches was measured and is worse here -- 0.400 s per run
+      // against 0.338, one launch of 128 ms among them: profiles/r06_streams.txt.)
+      ctx->stream_span = 0x80000000u;
       ctx->stream_spans = 1;
       ctx->stream_host = nullptr;
       ctx->stream_ptrs = static_cast<const uint64_t*>(ctx->hostptrs.p);
