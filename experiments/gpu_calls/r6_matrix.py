@@ -7,10 +7,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 O = os.path.join(ROOT, "gpurun_out", "r6_final")
+O2 = os.path.join(ROOT, "gpurun_out", "r6_final2")   # the last host-side changes (same kernel sources): the default line, push mode, whole-file calls
+
+
+def path_of(name):
+    p2 = os.path.join(O2, name)
+    return p2 if os.path.exists(p2) else os.path.join(O, name)
 
 
 def last_json(name):
-    p = os.path.join(O, name)
+    p = path_of(name)
     if not os.path.exists(p):
         return None
     lines = [l for l in open(p) if l.startswith("{")]
@@ -22,7 +28,7 @@ def main():
     d = last_json("bench_default.json")
     out.append("# Round 6 bench matrix (one MI355X; lc3/lp0/pb2, known-size headers, 4096 x 1 MiB per launch unless noted)\n")
     out.append("Every line: all units OK and the CRC-32 of every unit's output (computed on the GPU) equal to `zlib.crc32` of the regenerated plaintext.")
-    out.append("GB/s = decompressed output.  Source: `experiments/gpu_calls/r6_final.sh` (`gpurun_out/r6_final/*`; the JSON lines are kept as `profiles/r06_bench_*.json`).")
+    out.append("GB/s = decompressed output.  Source: `experiments/gpu_calls/r6_final.sh` and `r6_final2.sh` (`gpurun_out/r6_final*/*`; the JSON lines are kept as `profiles/r06_bench_*.json`).")
     out.append("Kernel source hash of every line: `%s`.\n" % (d["roofline"]["kernel_source_sha256"] if d else "?"))
     out.append("| workload | command | GB/s | kernel ms | note |")
     out.append("|---|---|---|---|---|")
@@ -68,11 +74,11 @@ def main():
                           (": %+.1f %% of lc3/lp0/pb2 on the same recipe" % (100.0 * (r["kernel_ms"] / base["kernel_ms"] - 1))) if base and r is not base else ""))
     s = last_json("streams_bench.json")
     if s:
-        out.append("| push mode: 4096 `.lzma` streams arriving in four pieces each from host memory, result buffers handed over (PCIe both ways) | `experiments/streams_bench.py` | %.2f | | wall %.3f s = writes %.3f + finish %.3f (round 5: 8.7 GB/s, finish 0.125 s); `profiles/r06_streams.txt` |"
+        out.append("| push mode: 4096 `.lzma` streams arriving in four pieces each from host memory, result buffers handed over (PCIe both ways) | `experiments/streams_bench.py` | %.2f | | wall %.3f s = writes %.3f + finish %.3f (round 5: 8.7 GB/s, finish 0.125 s; 12.2 .. 12.7 by box); `profiles/r06_streams.txt` |"
                    % (s["GBps"], s["seconds"], s["writes_s"], s["finish_s"]))
     for name, label in (("batch_api_lzma.txt", "one whole-file call, 4096 x 1 MiB `.lzma`, host buffers in, per-file result buffers out"),
                         ("batch_api_xz.txt", "one whole-file call, 1024 x 4 MiB `.xz`")):
-        p = os.path.join(O, name)
+        p = path_of(name)
         if os.path.exists(p):
             best = 0.0
             kms = ""
@@ -81,7 +87,7 @@ def main():
                 if m and float(m.group(1)) > best:
                     best, kms = float(m.group(1)), m.group(2)
             if best:
-                out.append("| %s | `experiments/batch_api_bench.py` | %.2f | %s | streamed launch (the waves deliver while they decode; input in two parts); PCIe-inclusive, never `value` |" % (label, best, kms))
+                out.append("| %s | `experiments/batch_api_bench.py` | %.2f | %s | streamed launch (the waves deliver while they decode; input in two parts); PCIe-inclusive, never `value`; round 5: 16.4 / 15.7 (`profiles/r06_batch_api.txt`) |" % (label, best, kms))
     text = "\n".join(out) + "\n"
     with open(os.path.join(ROOT, "profiles", "r06_bench_matrix.md"), "w") as f:
         f.write(text)

@@ -357,6 +357,71 @@ uint8_t* out_alloc(size_t n, bool pinned) {
   return reinterpret_cast<uint8_t*>(h + 1);
 }
 
+// count buffers at once (a batch call wants thousands): everything the pool holds is taken under ONE lock -- sixteen host threads taking
+// 4096 buffers one by one spent 10 ms of every whole-file call on this mutex (two acquisitions per buffer) --, what it does not hold is
+// allocated outside it on the host threads, the registry grows under one more.  out[k] = nullptr where memory could not be had; returns
+// false if any is.
+bool out_alloc_many(const size_t* n, size_t count, bool pinned, uint8_t** out) {
+  OutPool& p = out_pool();
+  std::vector<OutHdr*> h(count, nullptr);
+  try {
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      auto& m = pinned ? p.free_pinned : p.free_by_cap;
+      for (size_t k = 0; k < count; k++) {
+        const size_t cap = out_class(n[k]);
+        auto it = m.lower_bound(cap);
+        while (it != m.end() && it->second.empty()) it = m.erase(it);
+        if (it != m.end() && it->first <= std::max(cap * 2, cap + (size_t(1) << 16))) {
+          h[k] = it->second.back();
+          it->second.pop_back();
+          p.held -= size_t(h[k]->cap);
+        }
+      }
+    }
+    std::atomic<int> failed{0};
+    parallel_for(count, [&](size_t k) {
+      if (h[k]) return;
+      const size_t cap = out_class(n[k]);
+      if (pinned) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, sizeof(OutHdr) + cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+          (void)hipGetLastError();
+          failed.store(1);
+          return;
+        }
+        h[k] = static_cast<OutHdr*>(q);
+      } else {
+        h[k] = static_cast<OutHdr*>(malloc(sizeof(OutHdr) + cap));
+        if (!h[k]) {
+          failed.store(1);
+          return;
+        }
+      }
+      h[k]->cap = cap;
+      h[k]->pinned = pinned ? 1 : 0;
+    });
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.live.reserve(p.live.size() + count);
+    for (size_t k = 0; k < count; k++) {
+      out[k] = h[k] ? reinterpret_cast<uint8_t*>(h[k] + 1) : nullptr;
+      if (!h[k]) continue;
+      p.live.insert(h[k] + 1);
+      p.live_bytes += size_t(h[k]->cap);
+      h[k] = nullptr;   // (handed out)
+    }
+    p.peak_live = std::max(p.peak_live, p.live_bytes);
+    return failed.load() == 0;
+  } catch (const std::bad_alloc&) {  // (the registry could not grow: what is not registered yet is not handed out)
+    for (size_t k = 0; k < count; k++)
+      if (h[k]) {
+        hdr_free(h[k]);
+        out[k] = nullptr;
+      }
+    return false;
+  }
+}
+
 MILZMA_HOST_NS_END
 
 extern "C" void milzma_free(void* ptr) {

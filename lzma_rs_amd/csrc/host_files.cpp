@@ -283,6 +283,7 @@ MILZMA_HOST_NS_BEGIN
 int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const size_t* in_lens, const milzma_options* opt,
                  bool lzma2, milzma_output* outs) {
   ctx->last_paths = 0;
+  if (ctx) trace_mark(ctx, "batch: call begins");
   std::vector<milzma_unit> units;
   std::vector<uint32_t> owner;  // unit -> stream
   std::vector<size_t> hdr(n, 0);
@@ -335,6 +336,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     return MILZMA_INFRA_ERROR;
   };
   if (!ctx) return fail_all();
+  trace_mark(ctx, "batch: headers read, units planned");
   if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return fail_all();
   // Streamed round 0 (below) for batches it pays for: many files of about one size, all in the fast kernel's class.  Their output
   // slices then sit at ONE pitch (span cuts are computed from the unit's index and the pitch alone).
@@ -359,7 +361,7 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     if (all_fast && (ragged_ok || pitch * units.size() <= out_total + out_total / 4) && in_total + pitch * units.size() <= budget &&
         streamed_slot.try_take(ctx->device)) {
       size_t span = size_t(64) << 10;
-      if (const char* e = env_get("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 16, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 16));
+      if (const char* e = env_get("MILZMA_SPAN")) span = std::max<size_t>(size_t(1) << 12, round_up(size_t(strtoull(e, nullptr, 0)), size_t(1) << 12));
       while ((pitch + span) / span + 1 > milzma_ctx::kMaxSpans) span *= 2;
       geo.pitch = pitch;
       geo.span = span;
@@ -422,22 +424,13 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     std::vector<uint8_t*>& bufs = held.v;
     std::atomic<int> alloc_failed{0};
     bool direct = pinned_results_wanted();
-    if (direct) {
-      parallel_for(nu, [&](size_t k) {
-        bufs[k] = out_alloc(size_t(units[k].out_cap), true);
-        if (!bufs[k]) alloc_failed = 1;
-      });
-      if (alloc_failed) {
-        held.drop();
-        alloc_failed = 0;
-        direct = false;
-      }
+    std::vector<size_t> caps(nu);
+    for (uint32_t k = 0; k < nu; k++) caps[k] = size_t(units[k].out_cap);
+    if (direct && !out_alloc_many(caps.data(), nu, true, bufs.data())) {
+      held.drop();
+      direct = false;
     }
-    if (!direct)
-      parallel_for(nu, [&](size_t k) {
-        bufs[k] = out_alloc(size_t(units[k].out_cap));
-        if (!bufs[k]) alloc_failed = 1;
-      });
+    if (!direct && !out_alloc_many(caps.data(), nu, false, bufs.data())) alloc_failed = 1;
     // The input goes up in two parts (upload_leads / upload_rest above): the leads before the launch, everything while it runs.
     void* host_dev = nullptr;
     bool ok = !alloc_failed && ensure_progress(ctx);
@@ -454,13 +447,17 @@ int stream_batch(milzma_ctx* ctx, uint32_t n, const uint8_t* const* ins, const s
     if (!ok) (void)hipGetLastError();
     bool input_up = false;
     if (ok) {
-      trace_mark(ctx, "streamed: leads");
+      trace_mark(ctx, "streamed: result buffers and pointer table ready");
       ok = upload_leads(ctx, units, [&](size_t k) { return ins[owner[k]] + hdr[owner[k]]; }, work_stream(ctx));
+      trace_mark(ctx, "streamed: leads up");
     }
     if (ok) {
       __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 0u, __ATOMIC_RELEASE);
       ctx->stream_span = uint32_t(geo.span);
-      ctx->stream_spans = geo.spans;
+      // (Page-locked result buffers: nobody looks at the span counters before the kernel has ended, so only the first span is announced --
+      //  an announcement is a release fence at system scope, the XCD's L2 written back, and 4096 waves x 16 spans of them were most of what
+      //  the delivery cost the kernel: 234 -> ... ms, profiles/r06_batch_api.txt.  The turns are cut at every span as before.)
+      ctx->stream_spans = direct ? 1 : geo.spans;
       ctx->stream_host = static_cast<uint8_t*>(host_dev);
       ctx->stream_ptrs = direct ? static_cast<const uint64_t*>(ctx->hostptrs.p) : nullptr;
       ctx->stream_in_host = true;

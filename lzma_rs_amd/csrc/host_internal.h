@@ -139,7 +139,7 @@ struct milzma_ctx {
   // Streamed launches (the whole-file calls' progressive download): a caller that sets stream_span / stream_spans before the async
   // half asks for the batch's ONE fast launch to run time-sliced with span counters (kernels.h); stream_active says it happened.
   // progress: kMaxSpans counters in mapped host memory, written by the device, polled by SpanPump.
-  static constexpr uint32_t kMaxSpans = 64;
+  static constexpr uint32_t kMaxSpans = 256;
   uint32_t* progress = nullptr;
   uint32_t* progress_dev = nullptr;
   uint32_t stream_span = 0, stream_spans = 0;
@@ -212,6 +212,7 @@ void pin_release(PinBuf& b);
 unsigned host_threads();
 size_t out_class(size_t n);
 uint8_t* out_alloc(size_t n, bool pinned = false);
+bool out_alloc_many(const size_t* n, size_t count, bool pinned, uint8_t** out);   // (thousands at once: one lock, not two per buffer)
 LitClass classify(const milzma_ctx* ctx, const milzma_unit& u);
 bool ensure_progress(milzma_ctx* ctx);
 extern const char* const kEofMsg;
@@ -432,9 +433,20 @@ bool upload_leads(milzma_ctx* ctx, const std::vector<milzma_unit>& units, Src sr
   }
   if (!pin_reserve(ctx, ctx->pin_lead, total) || !dev_reserve(ctx, ctx->pack, total + 512)) return false;
   uint8_t* h = static_cast<uint8_t*>(ctx->pin_lead.p);
-  parallel_for(nu, [&](size_t k) { memcpy(h + so[k], src(k), size_t(ln[k])); });
-  return hip_ok(ctx, hipMemcpyAsync(ctx->pack.p, h, total, hipMemcpyHostToDevice, ws), "H2D leads") &&
-         move_units_impl(ctx, nu, ctx->pack.p, so.data(), ctx->in.p, dof.data(), ln.data(), ws) == MILZMA_OK;
+  // in four pieces: the host threads gather piece g + 1 while piece g crosses the link (round 6: the one copy behind the whole gather was
+  // 6 of this step's 16 ms at configs[1]'s size)
+  const uint32_t pieces = nu >= 64 ? 4 : 1;
+  for (uint32_t g = 0; g < pieces; g++) {
+    const uint32_t k0 = uint32_t(uint64_t(nu) * g / pieces), k1 = uint32_t(uint64_t(nu) * (g + 1) / pieces);
+    if (k1 == k0) continue;
+    parallel_for(k1 - k0, [&](size_t k) { memcpy(h + so[k0 + k], src(k0 + k), size_t(ln[k0 + k])); });
+    const size_t lo = size_t(so[k0]), hi = k1 < nu ? size_t(so[k1]) : total;
+    if (!hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->pack.p) + lo, h + lo, hi - lo, hipMemcpyHostToDevice, ws), "H2D leads")) {
+      (void)hipStreamSynchronize(ws);   // (the pieces already queued read pin_lead)
+      return false;
+    }
+  }
+  return move_units_impl(ctx, nu, ctx->pack.p, so.data(), ctx->in.p, dof.data(), ln.data(), ws) == MILZMA_OK;
 }
 
 // bounds: ascending offsets into the input buffer (pieces); fill(g) gathers piece g's bytes [bounds[g], bounds[g + 1]) into hin

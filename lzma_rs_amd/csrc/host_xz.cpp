@@ -618,7 +618,7 @@ int milzma_xz_decompress_batch_impl(milzma_ctx* ctx, uint32_t n, const uint8_t* 
         if (!alloc_failed) {
           __atomic_store_n(&ctx->progress[milzma_ctx::kMaxSpans], 0u, __ATOMIC_RELEASE);
           ctx->stream_span = uint32_t(geo.span);
-          ctx->stream_spans = geo.spans;
+          ctx->stream_spans = direct ? 1 : geo.spans;   // (page-locked result buffers: nobody reads the counters mid-kernel -- host_files.cpp)
           ctx->stream_host = static_cast<uint8_t*>(host_dev);
           ctx->stream_ptrs = direct ? static_cast<const uint64_t*>(ctx->hostptrs.p) : nullptr;
           ctx->stream_in_host = two_part;
