@@ -129,23 +129,28 @@ static bool regrow(milzma_streams* S, const std::vector<std::pair<uint32_t, uint
     S->units[i].out_cap = cap[i];
   }
   if (S->deliver) {   // the result buffers follow the slices (what has been delivered moves along: rare -- the first guess is generous)
-    std::atomic<int> failed{0};
-    parallel_for(want.size(), [&](size_t w) {
-      const uint32_t i = want[w].first;
-      One& o = S->s[i];
-      if (o.hcap >= cap[i]) return;
-      uint8_t* nb = out_alloc(size_t(cap[i]), true);
-      if (!nb) {
-        failed.store(1);
-        return;
+    std::vector<uint32_t> who;
+    std::vector<size_t> sizes;
+    for (const auto& w : want)
+      if (S->s[w.first].hcap < cap[w.first]) {
+        who.push_back(w.first);
+        sizes.push_back(size_t(cap[w.first]));
       }
-      const size_t have = o.hbuf ? size_t(std::min<uint64_t>(S->res[i].out_len, o.hcap)) : 0;
-      if (have) memcpy(nb, o.hbuf, have);
-      if (o.hbuf) milzma_free(o.hbuf);
-      o.hbuf = nb;
-      o.hcap = size_t(cap[i]);
-    });
-    if (failed.load()) {   // page-locked memory has run out: from here on finish copies (what was delivered so far is on the device too)
+    std::vector<uint8_t*> fresh_bufs(who.size(), nullptr);
+    const bool got = who.empty() || out_alloc_many(sizes.data(), who.size(), true, fresh_bufs.data());   // (the pool under one lock)
+    if (got)
+      parallel_for(who.size(), [&](size_t w) {
+        One& o = S->s[who[w]];
+        const size_t have = o.hbuf ? size_t(std::min<uint64_t>(S->res[who[w]].out_len, o.hcap)) : 0;
+        if (have) memcpy(fresh_bufs[w], o.hbuf, have);
+        if (o.hbuf) milzma_free(o.hbuf);
+        o.hbuf = fresh_bufs[w];
+        o.hcap = sizes[w];
+      });
+    else
+      for (uint8_t* b : fresh_bufs)
+        if (b) milzma_free(b);
+    if (!got) {   // page-locked memory has run out: from here on finish copies (what was delivered so far is on the device too)
       S->deliver = false;
       for (One& o : S->s) {
         if (o.hbuf) milzma_free(o.hbuf);
