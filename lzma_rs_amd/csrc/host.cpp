@@ -630,7 +630,9 @@ bool launch_class(milzma_ctx* ctx, LitClass cls, const std::vector<uint32_t>& or
     const hipError_t le = sliced
                               ? launch_fast_sliced(d_units, d_order + i, m, d_in, d_out, d_results, stream, ctx->lds_pad,
                                                    static_cast<uint32_t*>(ctx->flags.p) + (ctx->ev_used & 63u), ctx->slice_q.p, cap,
-                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow, feed, ctx->stream_span, ctx->stream_spans,
+                                                   ctx->slice_quantum, ctx->slice_mode > 1, ctx->slice_ctx.p, grow,
+                                                   feed ? (ctx->stream_feed ? 3u : 1u) : 0u,   // (bit 1: units parked for input deliver their last turn with their next launch)
+                                                   ctx->stream_span, ctx->stream_spans,
                                                    ctx->stream_active ? ctx->progress_dev : nullptr, ctx->stream_active ? ctx->stream_host : nullptr,
                                                    ctx->stream_active && ctx->stream_in_host ? ctx->progress_dev + milzma_ctx::kMaxSpans : nullptr,
                                                    ctx->stream_active ? ctx->stream_ptrs : nullptr,

@@ -42,7 +42,7 @@ size_t slice_ctx_bytes();  // per unit, the same for both instantiations
 size_t slice_queue_bytes(uint32_t cap);
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, bool feed, uint32_t span_bytes = 0,
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t feed, uint32_t span_bytes = 0,
                               uint32_t n_spans = 0, uint32_t* progress = nullptr, uint8_t* host_out = nullptr, uint32_t* in_ready = nullptr,
                               const uint64_t* host_ptrs = nullptr, const uint8_t* d_slab = nullptr, uint32_t slab_bytes = 0);
 // host_ptrs (device array, one entry per unit of the batch, or null): the unit's own destination in host memory (0: none)

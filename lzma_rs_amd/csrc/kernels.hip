@@ -98,7 +98,7 @@ size_t slice_queue_bytes(uint32_t cap) { return sizeof(SliceQueue) + size_t(cap)
 
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
                               milzma_result* d_results, hipStream_t stream, uint32_t lds_pad, uint32_t* d_flag, void* d_queue,
-                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, bool feed, uint32_t span_bytes,
+                              uint32_t cap, uint32_t quantum, bool always_park, void* d_ctxmem, bool grow, uint32_t feed, uint32_t span_bytes,
                               uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready, const uint64_t* host_ptrs,
                               const uint8_t* d_slab, uint32_t slab_bytes) {
   if (n == 0) return hipSuccess;
@@ -109,7 +109,7 @@ hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_orde
   const uint32_t resident = std::min(fast_resident_blocks(lds_pad), resident_blocks(kKernSliced, lds_pad));
   const uint32_t waves = std::min(n, resident);
   hipLaunchKernelGGL(slice_queue_init_kernel, dim3(64), dim3(256), 0, stream, q, ring, d_order, n, cap, quantum, always_park ? 1u : 0u, waves,
-                     d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem), grow ? 1u : 0u, feed ? 1u : 0u,
+                     d_units, d_in, d_out, d_results, d_flag, static_cast<uint32_t*>(d_ctxmem), grow ? 1u : 0u, feed,
                      uint32_t(slice_ctx_bytes() / sizeof(uint32_t)), progress ? span_bytes : 0u, n_spans, progress, host_out, progress ? in_ready : nullptr, progress ? host_ptrs : nullptr,
                      d_slab, slab_bytes);
   hipLaunchKernelGGL(decode_fast_asm_sliced_kernel, dim3(waves), dim3(kWave), lds_pad, stream, q);

@@ -245,7 +245,7 @@ uint32_t fast_resident_blocks(uint32_t) { return 16; }   // (a small chip: launc
 size_t slice_ctx_bytes() { return 64; }
 size_t slice_queue_bytes(uint32_t cap) { return size_t(cap) * 8 + 64; }
 hipError_t launch_fast_sliced(const milzma_unit* d_units, const uint32_t* d_order, uint32_t n, const uint8_t* d_in, uint8_t* d_out,
-                              milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void* d_ctxmem, bool grow, bool feed,
+                              milzma_result* d_results, hipStream_t stream, uint32_t, uint32_t*, void*, uint32_t, uint32_t, bool, void* d_ctxmem, bool grow, uint32_t feed,
                               uint32_t span_bytes, uint32_t n_spans, uint32_t* progress, uint8_t* host_out, uint32_t* in_ready,
                               const uint64_t* host_ptrs, const uint8_t* d_slab, uint32_t slab_bytes) {
   if (fake_hip_launch_fails()) return hipErrorLaunchFailure;
