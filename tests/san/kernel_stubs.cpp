@@ -12,7 +12,7 @@ uint32_t fast_resident_blocks(uint32_t) { return 4096; }
 size_t slice_ctx_bytes() { return 1; }
 size_t slice_queue_bytes(uint32_t cap) { return cap; }
 hipError_t launch_fast_sliced(const milzma_unit*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, milzma_result*, hipStream_t, uint32_t,
-                              uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool, bool, uint32_t, uint32_t, uint32_t*, uint8_t*, uint32_t*, const uint64_t*, const uint8_t*, uint32_t) { return hipErrorNoDevice; }
+                              uint32_t*, void*, uint32_t, uint32_t, bool, void*, bool, uint32_t, uint32_t, uint32_t, uint32_t*, uint8_t*, uint32_t*, const uint64_t*, const uint8_t*, uint32_t) { return hipErrorNoDevice; }
 uint32_t stream_lead_bytes(uint32_t in_len) { return in_len; }
 hipError_t launch_slab_init(uint8_t*, uint32_t, const uint32_t*, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_move_units(const uint8_t*, uint8_t*, const uint64_t*, uint32_t, hipStream_t) { return hipErrorNoDevice; }
