@@ -79,7 +79,7 @@ def binaries(tmp_path_factory):
     if not os.path.exists(CLANG):
         pytest.skip("no clang with sanitizer runtimes in this image")
     out = str(tmp_path_factory.mktemp("pipeline_build"))
-    r = subprocess.run(["make", "-C", SAN, "-s", "-j2", "OUT=" + out, out + "/pipeline_asan", out + "/pipeline_tsan"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", SAN, "-s", "-j4", "OUT=" + out, out + "/pipeline_asan", out + "/pipeline_tsan"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return {"asan": out + "/pipeline_asan", "tsan": out + "/pipeline_tsan"}
 
@@ -109,16 +109,59 @@ TSAN_SKIPS = {"mutations-default", "mutations-streamed", "groups-streamed", "gen
 ASAN_SKIPS = {"streamed-three-devices", "replicas-copy-home", "groups-streamed"}   # (ThreadSanitizer's, or covered by a neighbour)
 
 
+def _skipped(san, path):
+    return (san == "tsan" and path in TSAN_SKIPS) or (san == "asan" and path in ASAN_SKIPS)
+
+
+FAULT_RUNS = [("asan", "default"), ("asan", "streamed"), ("asan", "multi-two-devices"), ("tsan", "streamed")]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_")}
+    env.update(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+    return env
+
+
+@pytest.fixture(scope="module")
+def runs(binaries, inputs):
+    """Every run of the matrix is a process of its own that shares nothing with the others: they are all started here, four at a time (the
+    container has 8 CPUs; a run keeps one to three of them busy), and each test below only waits for its own and judges it -- the module
+    takes a third of the time the runs take one after another."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=int(os.environ.get("MILZMA_TEST_SAN_JOBS", "4")))
+    jobs = {}
+
+    def start(key, argv, env):
+        jobs[key] = pool.submit(subprocess.run, argv, capture_output=True, text=True, env=env, timeout=1800)
+
+    # (the slow ones first: ThreadSanitizer's)
+    for san in ("tsan", "asan"):
+        for path in sorted(MATRIX):
+            if _skipped(san, path):
+                continue
+            env = _clean_env()
+            env.update(MATRIX[path])
+            rounds = "1" if san == "tsan" or "PIPELINE_BIG" in MATRIX[path] or "PIPELINE_MUTATIONS" in MATRIX[path] else "2"
+            start(("matrix", san, path), [binaries[san], inputs, rounds, "11"], env)
+    for san, path in FAULT_RUNS:
+        env = _clean_env()
+        # (multi-two-devices: also the multi-device whole-file batch and the one-ingest-point unit call -- there fault injection found a
+        #  launch still writing the caller's buffer after its failed call had returned: the wait half drains the device on every way out now)
+        env.update(MATRIX.get(path, {"FAKE_HIP_DEVICES": "2", "PIPELINE_FAULTS_MULTI": "1"}))
+        env["PIPELINE_FAULTS"] = "120"
+        if san == "tsan":
+            env["PIPELINE_FAULT_STRIDE"] = "3"     # (every third call: ThreadSanitizer's runs are the slow ones)
+        start(("faults", san, path), [binaries[san], inputs, "1", "5"], env)
+    yield jobs
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
 @pytest.mark.parametrize("san", ["asan", "tsan"])
 @pytest.mark.parametrize("path", sorted(MATRIX))
-def test_host_pipeline_under_sanitizers(binaries, inputs, san, path):
-    if (san == "tsan" and path in TSAN_SKIPS) or (san == "asan" and path in ASAN_SKIPS):
+def test_host_pipeline_under_sanitizers(runs, san, path):
+    if _skipped(san, path):
         pytest.skip("the other sanitizer's share of the matrix")
-    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_")}
-    env.update(MATRIX[path])
-    env.update(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
-    rounds = "1" if san == "tsan" or "PIPELINE_BIG" in MATRIX[path] or "PIPELINE_MUTATIONS" in MATRIX[path] else "2"
-    r = subprocess.run([binaries[san], inputs, rounds, "11"], capture_output=True, text=True, env=env, timeout=900)
+    r = runs[("matrix", san, path)].result()
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0, tail
     assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
@@ -128,23 +171,16 @@ def test_host_pipeline_under_sanitizers(binaries, inputs, san, path):
     assert int(stats["compared"]) >= 200
 
 
-@pytest.mark.parametrize("san,path", [("asan", "default"), ("asan", "streamed"), ("asan", "multi-two-devices"), ("tsan", "streamed")])
-def test_host_pipeline_fault_injection(binaries, inputs, san, path):
+@pytest.mark.parametrize("san,path", FAULT_RUNS)
+def test_host_pipeline_fault_injection(runs, san, path):
     """Every fallible runtime call of a batch -- allocations, copies, stream and event creation, kernel launches: about a hundred per call --
     fails once (tests/san/fake_hip.cpp: fake_hip_fail_at), one run per call and entry point.  Whatever fails, every file comes back either as
     the oracle has it or with an infrastructure error and a text; no crash, no hang (the waves' input-ready word is set on failed uploads
     too), and LeakSanitizer finds nothing left behind (it found an event leaked by milzma_create's own failure path)."""
-    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_")}
-    # (multi-two-devices: also the multi-device whole-file batch and the one-ingest-point unit call -- there fault injection found a
-    #  launch still writing the caller's buffer after its failed call had returned: the wait half drains the device on every way out now)
-    env.update(MATRIX.get(path, {"FAKE_HIP_DEVICES": "2", "PIPELINE_FAULTS_MULTI": "1"}))
     # (ThreadSanitizer's run: a failed piece of the second upload used to leave the earlier pieces in flight -- writing the input buffer
     #  the files decoded on their own were about to use --, and a launch that could not be made a streamed one ran on input that was
     #  not there yet: both found here, both fixed)
-    env.update(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1", PIPELINE_FAULTS="120")
-    if san == "tsan":
-        env["PIPELINE_FAULT_STRIDE"] = "3"     # (every third call: ThreadSanitizer's runs are the slow ones)
-    r = subprocess.run([binaries[san], inputs, "1", "5"], capture_output=True, text=True, env=env, timeout=900)
+    r = runs[("faults", san, path)].result()
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and "runtime error" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr, tail
     last = r.stdout.strip().splitlines()[-1]
