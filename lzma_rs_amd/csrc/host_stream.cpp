@@ -210,18 +210,29 @@ static bool feed_round(milzma_streams* S, std::vector<uint32_t> active, bool las
     const size_t need = in_total + 512;
     if ((ctx->pin_in.cap < need && !pin_reserve(ctx, ctx->pin_in, need + need / 4)) || (ctx->in.cap < need && !dev_reserve(ctx, ctx->in, need + need / 4)))
       return false;
-    parallel_for(active.size(), [&](size_t a) {
-      const uint32_t i = active[a];
-      One& o = S->s[i];
-      uint8_t* dst = static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off;
-      const size_t view = size_t(S->units[i].in_len), own = std::min(view, o.pending.size());
-      if (own) memcpy(dst, o.pending.data(), own);
-      if (view > own) memcpy(dst + own, o.ext, view - own);
-    });
+    // in four pieces: the host threads gather piece g + 1 while piece g crosses the link (the gather is 4 ms of a write call at configs[1]'s
+    // size, the copy 7: profiles/r06_streams.txt)
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return false;
+    const size_t pieces = active.size() >= 64 ? 4 : 1;
+    for (size_t g = 0; g < pieces; g++) {
+      const size_t a0 = active.size() * g / pieces, a1 = active.size() * (g + 1) / pieces;
+      if (a1 == a0) continue;
+      parallel_for(a1 - a0, [&](size_t a) {
+        const uint32_t i = active[a0 + a];
+        One& o = S->s[i];
+        uint8_t* dst = static_cast<uint8_t*>(ctx->pin_in.p) + S->units[i].in_off;
+        const size_t view = size_t(S->units[i].in_len), own = std::min(view, o.pending.size());
+        if (own) memcpy(dst, o.pending.data(), own);
+        if (view > own) memcpy(dst + own, o.ext, view - own);
+      });
+      const size_t lo = size_t(S->units[active[a0]].in_off), hi = a1 < active.size() ? size_t(S->units[active[a1]].in_off) : in_total;
+      if (!hip_ok(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->in.p) + lo, static_cast<const uint8_t*>(ctx->pin_in.p) + lo, hi - lo,
+                                      hipMemcpyHostToDevice, work_stream(ctx)), "H2D views")) {
+        (void)hipStreamSynchronize(work_stream(ctx));   // (the pieces already queued read pin_in)
+        return false;
+      }
+    }
     trace_mark(ctx, "streams: views gathered");
-    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice") ||
-        !hip_ok(ctx, hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_total, hipMemcpyHostToDevice, work_stream(ctx)), "H2D views"))
-      return false;
     for (uint32_t i = 0; i < S->n; i++) {
       uint8_t k = S->units[i].kind & (MILZMA_KIND_START | 0x0Fu);
       if (!is_active[i]) {
