@@ -342,7 +342,9 @@ print("ok")
     # round 5 (profiles/r05_kernel_ab.txt): the loop as round 4 shipped it (the symbol in an SGPR, four instructions per shadow), and the
     # forms that were measured and rejected: single decisions all scalar, tree walks in form A with shadows, 2^24 in an SGPR
     {"MILZMA_GEN_SYM_M0": "0", "MILZMA_GEN_SHADOW": "4"}, {"MILZMA_GEN_S1": "single"}, {"MILZMA_GEN_FORMB": "none", "MILZMA_GEN_FORMA2": "1"},
-    {"MILZMA_GEN_K24S": "1"}], ids=lambda k: "+".join(sorted(x[11:] for x in k)))
+    {"MILZMA_GEN_K24S": "1"},
+    # round 6: the direct-bit chains on the vector ALU
+    {"MILZMA_GEN_VDIRECT": "1"}], ids=lambda k: "+".join(sorted(x[11:] for x in k)))
 def test_emulated_loop_under_measured_and_rejected_knobs(knobs):
     """The generator switches of round 4's A/Bs (profiles/r04_kernel_ab.txt sections 3-4: scalar bookkeeping in shadows, the two deferred
     tree updates, range >> 11 on the scalar ALU; and the loop WITHOUT the batch that shipped) still generate loops that decode bit-exactly:

@@ -48,7 +48,7 @@ struct Ins {
   X(v_cmp_ge_u32) X(v_cmp_le_u32) X(v_cmp_ne_u32) X(v_lshl_or_b32) X(v_lshl_add_u32) X(v_add_lshl_u32)                 \
   X(v_and_or_b32) X(v_add3_u32) X(v_bfe_u32) X(v_ffbh_u32) X(v_cvt_f32_u32) X(v_cvt_u32_f32) X(v_rcp_f32)              \
   X(v_add_f32) X(v_mul_f32) X(v_min_u32) X(v_max_u32) X(v_max_i32) X(v_movrels_b32) X(v_movreld_b32) X(v_bfi_b32)                   \
-  X(v_alignbit_b32) X(v_or3_b32) X(v_xad_u32) X(v_sub_co_u32) X(v_mbcnt_lo_u32_b32) X(v_mbcnt_hi_u32_b32)              \
+  X(v_alignbit_b32) X(v_or3_b32) X(v_xad_u32) X(v_sub_co_u32) X(v_addc_co_u32) X(v_mbcnt_lo_u32_b32) X(v_mbcnt_hi_u32_b32)              \
   X(ds_read_b128) X(ds_write_b128) X(ds_read_b32) X(ds_write_b32) X(ds_read_u8) X(ds_write_b8) X(ds_read_b64)          \
   X(ds_write_b64) X(buffer_load_ubyte) X(buffer_store_byte) X(buffer_load_dword) X(buffer_store_dword)                 \
   X(buffer_load_dwordx2) X(buffer_load_dwordx4) X(buffer_store_dwordx2) X(buffer_store_dwordx4)                        \
@@ -362,6 +362,19 @@ long run(Emu& e, int start, long max_steps) {
           uint32_t a = rl(e, I.a[2], l, 0), b = rl(e, I.a[3], l, 1);
           tmp[l] = a - b;
           if (b > a) m |= 1ull << l;
+        }
+        memcpy(e.v[d], tmp, sizeof(tmp));
+        ws64(e, I.a[1], m);
+      } break;
+      case OP_v_addc_co_u32: {  // vdst, sdst(carry out), a, b, ssrc(carry in)
+        uint32_t d = vreg(e, I.a[0], 3);
+        const uint64_t cin = rs64(e, I.a[4]);
+        uint64_t m = 0;
+        uint32_t tmp[64];
+        for (int l = 0; l < 64; l++) {
+          const uint64_t sum = uint64_t(rl(e, I.a[2], l, 0)) + uint64_t(rl(e, I.a[3], l, 1)) + ((cin >> l) & 1u);
+          tmp[l] = uint32_t(sum);
+          if (sum >> 32) m |= 1ull << l;
         }
         memcpy(e.v[d], tmp, sizeof(tmp));
         ws64(e, I.a[1], m);

@@ -184,6 +184,17 @@ ALIGN_STUBS = int(os.environ.get("MILZMA_GEN_ALIGN_STUBS", "0"))
 #       out-of-line paths -- start a fetch line for free.  (Not inside the direct-bit chains: their entries are computed from equal strides.)
 ALIGN_FREE = int(os.environ.get("MILZMA_GEN_ALIGN_FREE", "0"))
 K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
+#   VDIRECT (round 6): the direct-bit chains on the VECTOR ALU, on (range, code, accumulator) in VGPRs that every lane holds alike: per bit
+#       v_lshrrev range / v_addc acc (the previous bit's borrow) / v_sub_co / v_min -- four VOP2 instructions on vector registers only (2.3
+#       cycles of the vector pipe each, profiles/r05_pipe_prices.json) where the scalar form takes four scalar instructions (4.1 cycles of the
+#       scalar pipe each: the pipe that binds since the walks' symbol lives in m0).  min(code, code - range) IS the new code (the difference
+#       wraps above code exactly when code < range), so only the accumulator reads vcc -- two instructions behind the v_sub_co that wrote
+#       it (gfx940: a VALU read of an SGPR a VALU wrote needs two wait states).  Into the chain: three moves; out of it: the last borrow
+#       and three v_readfirstlane.
+#       VDIRECT_S: the LAST so many bits of every chain stay on the scalar ALU (the pipes' loads meet somewhere in between): the chain then crosses
+#       from the vector registers to (range, code, t4) in front of them, else at its end.
+VDIRECT = os.environ.get("MILZMA_GEN_VDIRECT", "0") == "1"
+VDIRECT_S = int(os.environ.get("MILZMA_GEN_VDIRECT_S", "0"))
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 # Where the loop's code falls in the 32-byte instruction fetch lines is worth +-1.2 % (round 5, profiles/r05_kernel_ab.txt section 4: the loop 64-byte
 # aligned + 0 / 2 dwords 224.5 ms, + 4 / 6 dwords 222.4, + 8 / 10 225.0, + 12 / 14 223.0: period 32 bytes).  Left to wherever the compiler's code in front
@@ -222,6 +233,7 @@ if STATE_TBL:
 # (VB2 = tbl_b >> 8 lives in VKTOP's register, which is free when every range test is scalar; with a vector-side test it is recomputed where
 #  it is used: one vector instruction per match)
 DISP2 = DISP2 and DISPMAD and DIRECT8
+VDIRECT = VDIRECT and DISP2 and NBPRE
 VB2_INLINE = DISP2 and not NORM_S >= {"tree", "single", "lit", "direct"}
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
 LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
@@ -820,9 +832,16 @@ class Gen:
         self.norm(to)
 
     @role("core")
-    def direct_bit(self, acc, test=True):
+    def direct_bit(self, acc, test=True, vec=False):
         """RangeDecoder::get_bit (rangecoder.rs:71-82): acc = 2 * acc + (bit == 0).  test=False: the caller knows where the
         normalisations fall (DIRECT8)."""
+        if vec:
+            assert not test
+            self.e("v_lshrrev_b32 {vr}, 1, {vr}")
+            self.e("v_addc_co_u32 {va}, vcc, {va}, {va}, vcc")     # (the bit before this one; entered with vcc = 0)
+            self.e("v_sub_co_u32 {vx}, vcc, {vb}, {vr}")           # vcc = code < range
+            self.e("v_min_u32 {vb}, {vb}, {vx}")                   # code - range wraps above code exactly when code < range
+            return
         self.e("s_lshr_b32 {range}, {range}, 1")
         self.e("s_sub_u32 {sc1}, {code}, {range}")
         self.e("s_cselect_b32 {code}, {code}, {sc1}")
@@ -831,7 +850,7 @@ class Gen:
             self.norm(kind="direct")
 
     @role("normstub")
-    def direct_norm(self, mark=None):
+    def direct_norm(self, mark=None, vec=False):
         """RangeDecoder::normalize (rangecoder.rs:59-69), unconditional and inline: range < 2^24 is known here"""
         e, L = self.e, self.L
         k = self.new("DN")
@@ -842,8 +861,18 @@ class Gen:
             e("s_cbranch_scc1 " + L("Xeof"))
         if not NBPRE:
             e("v_readlane_b32 {n1}, {winb}, {off}")
-        e("s_lshl_b64 " + RC + ", " + RC + ", 8")
-        e("s_or_b32 {code}, {code}, " + ("{nb}" if NBPRE else "{n1}"))
+        if vec and not VDIRECT_S:
+            e("v_lshlrev_b32 {vr}, 8, {vr}")
+            e("v_lshl_or_b32 {vb}, {vb}, 8, {nb}")
+        elif vec:                                # (chains of both forms: every normalisation block the same size AND the same number of
+            e("v_lshlrev_b32 {vr}, 8, {vr}")     #  instructions -- the emulator's addresses count instructions --: 28 bytes, six instructions)
+            e("v_lshlrev_b32 {vb}, 8, {vb}")
+            e("v_or_b32 {vb}, {nb}, {vb}")
+        else:
+            if VDIRECT and VDIRECT_S:
+                e("s_nop 0")
+            e("s_lshl_b64 " + RC + ", " + RC + ", 8")
+            e("s_or_b32 {code}, {code}, " + ("{nb}" if NBPRE else "{n1}"))
         e("s_add_u32 {off}, {off}, 1")
         if NBPRE:
             e("v_readlane_b32 {nb}, {winb}, {off}")
@@ -857,6 +886,16 @@ class Gen:
             self.lab(k)
             e("s_call_b64 " + RET + ", " + L("refill"))
             e("s_branch " + L(k + "r"))
+
+    @role("book")
+    def direct_cross(self):
+        """VDIRECT: from the chain's vector registers to (range, code, t4) -- with the last bit's borrow, which the next bit block would
+        have added (two instructions between the v_sub_co that wrote vcc and its reader, one between a VALU write and its v_readfirstlane)"""
+        e = self.e
+        e("v_readfirstlane_b32 {range}, {vr}")
+        e("v_addc_co_u32 {va}, vcc, {va}, {va}, vcc")
+        e("v_readfirstlane_b32 {code}, {vb}")
+        e("v_readfirstlane_b32 {t4}, {va}")
 
     # ---- pending short match ---------------------------------------------------------------------------
     def finish_pending(self, have_t6=False, prof=None, extract=True):
@@ -939,6 +978,13 @@ class Gen:
             e("v_add_u32 {vb}, -5, {VT1}")                 # n
             e("v_mul_u32_u24 {vt}, (" + L("db_e") + "-" + L("db_s") + "), {vb}")
             e("v_sub_u32 {tbl_b}, " + L("dend0") + "-" + L("base") + ", {vt}")
+            if VDIRECT and VDIRECT_S:                      # (an entry with more than VDIRECT_S bits to go lies in front of the chain's crossing block)
+                e("v_mov_b32 {vx}, " + L("dt_e") + "-" + L("dt_s"))
+                e("v_cmp_lt_u32 vcc, %d, {vb}" % VDIRECT_S)
+                e("s_nop 0")
+                e("s_nop 0")
+                e("v_cndmask_b32 {vx}, 0, {vx}, vcc")
+                e("v_sub_u32 {tbl_b}, {tbl_b}, {vx}")
             if DISP2:                                      # B2 = offset + n * chain stride (see distance_tables)
                 e("v_mad_u32_u24 {tbl_b}, {vb}, {VCH}, {tbl_b}")
             e("v_lshl_or_b32 {tbl_b}, {tbl_b}, 8, {vb}")
@@ -1437,7 +1483,14 @@ class Gen:
                 e("v_mad_u32_u24 {VT2}, {t6}, {VCH}, {VB2}")     # B2 + clz * stride
             e("v_bfe_u32 {VT1}, {VT0}, 3, 5")
             e("v_mad_i32_i24 {VT0}, {VT1}, {VNDN}, {VT2}")
-            e("s_mov_b32 {t4}, 0")
+            if VDIRECT:
+                assert not any(x[2] for x in self.q)             # (nothing queued reads vcc: the chains use it)
+                e("s_mov_b64 vcc, 0")
+                e("v_mov_b32 {vr}, {range}")
+                e("v_mov_b32 {vb}, {code}")
+                e("v_mov_b32 {va}, 0")
+            if not VDIRECT or VDIRECT_S:
+                e("s_mov_b32 {t4}, 0")
             e("v_readlane_b32 {t2}, {tbl_a}, {sym}")
             e("v_readlane_b32 {t3}, {VT0}, {sym}")
         else:
@@ -1477,16 +1530,23 @@ class Gen:
             for v in range(8):
                 lab("dchain%d" % v)
                 if v >= 2:                                   # (every chain carries four normalisation blocks, so that they are all
-                    self.direct_norm()                       #  the same size: this one is never reached)
+                    self.direct_norm(vec=VDIRECT)            #  the same size: this one is never reached)
                 for r in range(25, -1, -1):                  # r = direct bits left after this one
                     mark = v == 0 and r == 25
+                    vec = VDIRECT and r >= VDIRECT_S
                     if mark:
                         lab("db_s")
-                    self.direct_bit(R("t4"), test=False)
+                    self.direct_bit(R("t4"), test=False, vec=vec)
                     if mark:
                         lab("db_e")
                     if r % 8 == v:
-                        self.direct_norm(mark="dn" if (v == 0 and r == 24) else None)
+                        self.direct_norm(mark="dn" if (v == 0 and r == 24) else None, vec=vec)
+                    if VDIRECT and VDIRECT_S and r == VDIRECT_S:
+                        if v == 0:
+                            lab("dt_s")
+                        self.direct_cross()
+                        if v == 0:
+                            lab("dt_e")
                 lab("dend%d" % v)
                 e("s_branch " + L("direct_done"))
                 lab("dtr_small%d" % v)                       # slots below 14 land here (no direct bits; chain = clz)
@@ -1500,6 +1560,8 @@ class Gen:
         self.sec = "align"
         self.no_align = False
         lab("direct_done")
+        if VDIRECT and not VDIRECT_S:
+            self.direct_cross()
         written = False
         for i in range(4):
             if "wb" in SSHADOW and i == 2 and not self.q:    # (the pos_slot tree's update went into the shadows of levels 0 and 1)
