@@ -132,23 +132,35 @@
   "v_readlane_b32 s76, %[a4], m0\n\t" "v_readlane_b32 s77, %[a5], m0\n\t" "v_readlane_b32 s78, %[a6], m0\n\t" "v_readlane_b32 s79, %[a7], m0\n\t"
 #define BODY_VRL_M0 "s_mov_b32 m0, 5\n\t" REP4(RLM8)
 
+// ---- round 6: the VDIRECT direct-bit block (tools/gen_fast_loop.py) and the scalar block it stands for, as the DEPENDENT chains they are in the loop ----
+#define F_VSUBCO(r) "v_sub_co_u32 %[" #r "], vcc, %[k], %[" #r "]\n\t"
+#define BODY_VSUBCO REP4(F_VSUBCO(a0) F_VSUBCO(a1) F_VSUBCO(a2) F_VSUBCO(a3) F_VSUBCO(a4) F_VSUBCO(a5) F_VSUBCO(a6) F_VSUBCO(a7))
+#define F_VMIN(r) "v_min_u32 %[" #r "], %[k], %[" #r "]\n\t"
+#define BODY_VMIN REP4(F_VMIN(a0) F_VMIN(a1) F_VMIN(a2) F_VMIN(a3) F_VMIN(a4) F_VMIN(a5) F_VMIN(a6) F_VMIN(a7))
+#define VDB "v_lshrrev_b32 %[a0], 1, %[a0]\n\t" "v_addc_co_u32 %[a1], vcc, %[a1], %[a1], vcc\n\t" "v_sub_co_u32 %[a2], vcc, %[a3], %[a0]\n\t" "v_min_u32 %[a3], %[a3], %[a2]\n\t"
+#define BODY_VDBLOCK REP4(VDB VDB) REP4(VDB VDB)
+#define SDB "s_lshr_b32 s66, s66, 1\n\t" "s_sub_u32 s75, s67, s66\n\t" "s_cselect_b32 s67, s67, s75\n\t" "s_addc_u32 s87, s87, s87\n\t"
+#define BODY_SDBLOCK REP4(SDB SDB) REP4(SDB SDB)
+
 #define OPS \
   : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7) \
   : [k] "v"(k) \
   : "s66", "s67", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "m0", "scc", "vcc"
 
 enum { kVADD, kVMUL24, kVLSHR, kVSUBS, kVMAD24, kVBFE, kVMULLO, kVREADLANE, kVCMP, kVCNDMASK, kSADD, kSMUL, kSCSEL64, kSCMPBR, kBR, kTAKEN,
-       kMIX_VS, kDECMIX, kVRL_CONST, kVRFL, kVLSHR_S, kVADD_S, kVSUB_V, kVMUL24_S, kVMAD24_S, kVBFE_S, kVCND_VCC, kVCMP_VCC_S, kVCMP_VCC_V, kVMOV_S, kVMOV_C, kVAND_L, kVXOR, kVLSHLOR, kVLSHLADD_S, kVASHR, kSADDC, kSLSHL64, kPAIR_VCC, kPAIR_SGPR, kVCND_VCC64, kVCND_AFTER, kVRL_M0, kCount };
+       kMIX_VS, kDECMIX, kVRL_CONST, kVRFL, kVLSHR_S, kVADD_S, kVSUB_V, kVMUL24_S, kVMAD24_S, kVBFE_S, kVCND_VCC, kVCMP_VCC_S, kVCMP_VCC_V, kVMOV_S, kVMOV_C, kVAND_L, kVXOR, kVLSHLOR, kVLSHLADD_S, kVASHR, kSADDC, kSLSHL64, kPAIR_VCC, kPAIR_SGPR, kVCND_VCC64, kVCND_AFTER, kVRL_M0, kVSUBCO, kVMIN, kVDBLOCK, kSDBLOCK, kCount };
 static const char* kNames[kCount] = {"v_add_u32", "v_mul_u32_u24", "v_lshrrev_b32", "v_sub_u32 (sgpr src)", "v_mad_u32_u24", "v_bfe_u32", "v_mul_lo_u32",
                                      "v_readlane_b32", "v_cmp_eq_u32 -> sgpr pair", "v_cndmask_b32 (sgpr mask)", "s_add_u32", "s_mul_i32", "s_cselect_b64",
                                      "s_cmp + s_cbranch (not taken)", "s_cbranch (not taken)", "s_branch (taken)", "mix 1 V : 1 S", "form-B decision blend",
     "v_readlane_b32 (const lane)", "v_readfirstlane_b32", "v_lshrrev_b32 (sgpr src)", "v_add_u32 (sgpr src)", "v_sub_u32 (vgpr srcs)", "v_mul_u32_u24 (sgpr src)", "v_mad_u32_u24 (sgpr src)", "v_bfe_u32 (sgpr src)", "v_cndmask_b32 (vcc, e32)", "v_cmp_eq_u32 vcc (sgpr src)", "v_cmp_eq_u32 vcc (vgpr srcs)", "v_mov_b32 (from sgpr)", "v_mov_b32 (inline const)", "v_and_b32 (32-bit literal)", "v_xor_b32", "v_lshl_or_b32", "v_lshl_add_u32 (sgpr src)", "v_ashrrev_i32", "s_addc_u32", "s_lshl_b64",
-    "v_cmp vcc + 2 fillers + v_cndmask vcc", "the same through an SGPR pair (e64)", "v_cndmask_b32_e64 (vcc)", "v_cndmask_b32 vcc after a v_cmp", "v_readlane_b32 (m0 lane)"};
+    "v_cmp vcc + 2 fillers + v_cndmask vcc", "the same through an SGPR pair (e64)", "v_cndmask_b32_e64 (vcc)", "v_cndmask_b32 vcc after a v_cmp", "v_readlane_b32 (m0 lane)",
+    "v_sub_co_u32 (vcc out)", "v_min_u32", "VDIRECT bit block (dependent)", "scalar bit block (dependent)"};
 // instructions of the body per iteration, split by pipe: {valu, salu, branch}
 static const int kCounts[kCount][3] = {{32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0},
                                        {0, 32, 0}, {0, 32, 0}, {0, 32, 0}, {0, 16, 16}, {0, 0, 32}, {0, 0, 32}, {16, 16, 0}, {20, 16, 4},
     {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {32, 0, 0}, {0, 32, 0}, {0, 32, 0},
-    {64, 0, 0}, {64, 0, 0}, {32, 0, 0}, {33, 0, 0}, {32, 1, 0}};
+    {64, 0, 0}, {64, 0, 0}, {32, 0, 0}, {33, 0, 0}, {32, 1, 0},
+    {32, 0, 0}, {32, 0, 0}, {64, 0, 0}, {0, 64, 0}};
 
 template <int VAR>
 __global__ __launch_bounds__(64) void body(uint64_t* out, int iters) {
@@ -202,7 +214,11 @@ __global__ __launch_bounds__(64) void body(uint64_t* out, int iters) {
     else if constexpr (VAR == kPAIR_SGPR) RUN(BODY_PAIR_SGPR);
     else if constexpr (VAR == kVCND_VCC64) RUN(BODY_VCND_VCC64);
     else if constexpr (VAR == kVCND_AFTER) RUN(BODY_VCND_AFTER);
-    else RUN(BODY_VRL_M0);
+    else if constexpr (VAR == kVRL_M0) RUN(BODY_VRL_M0);
+    else if constexpr (VAR == kVSUBCO) RUN(BODY_VSUBCO);
+    else if constexpr (VAR == kVMIN) RUN(BODY_VMIN);
+    else if constexpr (VAR == kVDBLOCK) RUN(BODY_VDBLOCK);
+    else RUN(BODY_SDBLOCK);
   }
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
   if (threadIdx.x == 0) out[blockIdx.x] = (t1 - t0) + (uint64_t)((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345);

@@ -185,12 +185,13 @@ ALIGN_STUBS = int(os.environ.get("MILZMA_GEN_ALIGN_STUBS", "0"))
 ALIGN_FREE = int(os.environ.get("MILZMA_GEN_ALIGN_FREE", "0"))
 K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
 #   VDIRECT (round 6): the direct-bit chains on the VECTOR ALU, on (range, code, accumulator) in VGPRs that every lane holds alike: per bit
-#       v_lshrrev range / v_addc acc (the previous bit's borrow) / v_sub_co / v_min -- four VOP2 instructions on vector registers only (2.3
-#       cycles of the vector pipe each, profiles/r05_pipe_prices.json) where the scalar form takes four scalar instructions (4.1 cycles of the
-#       scalar pipe each: the pipe that binds since the walks' symbol lives in m0).  min(code, code - range) IS the new code (the difference
-#       wraps above code exactly when code < range), so only the accumulator reads vcc -- two instructions behind the v_sub_co that wrote
-#       it (gfx940: a VALU read of an SGPR a VALU wrote needs two wait states).  Into the chain: three moves; out of it: the last borrow
-#       and three v_readfirstlane.
+#       v_lshrrev range / v_addc acc (the previous bit's borrow) / v_sub_co / v_min -- four VOP2 instructions on vector registers only where
+#       the scalar form takes four scalar instructions.  min(code, code - range) IS the new code (the difference wraps above code exactly
+#       when code < range), so only the accumulator reads vcc -- two instructions behind the v_sub_co that wrote it (gfx940: a VALU read of an
+#       SGPR a VALU wrote needs two wait states).  Into the chain: three moves; out of it: the last borrow and three v_readfirstlane.
+#       MEASURED (profiles/r06_kernel_ab.txt section 3): nothing -- v_sub_co, v_min and v_addc are 4.3-cycle forms like the scalar pipe's 4.1
+#       (experiments/microbench/pipe_peaks.hip: the vector block 16.7 cycles per bit and SIMD at four waves, the scalar one 16.5), and moving
+#       a sixth of the scalar instructions to the other pipe, all of them or any share, leaves the kernel where it was.  Off.
 #       VDIRECT_S: the LAST so many bits of every chain stay on the scalar ALU (the pipes' loads meet somewhere in between): the chain then crosses
 #       from the vector registers to (range, code, t4) in front of them, else at its end.
 VDIRECT = os.environ.get("MILZMA_GEN_VDIRECT", "0") == "1"
