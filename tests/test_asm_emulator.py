@@ -335,7 +335,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("knobs", [
+KNOB_SETS = [
     {"MILZMA_GEN_SSHADOW": "state,rep,wb"}, {"MILZMA_GEN_LENDEFER": "1"}, {"MILZMA_GEN_LENDEFER": "1", "MILZMA_GEN_ALIGNLAZY": "1"},
     {"MILZMA_GEN_R11S": "tree"}, {"MILZMA_GEN_SWAP2": "0", "MILZMA_GEN_DISPMAD": "0", "MILZMA_GEN_MLGUARD": "0", "MILZMA_GEN_EARLYLDS": "0",
                                   "MILZMA_GEN_NBPRE": "0"},
@@ -343,14 +343,34 @@ print("ok")
     # forms that were measured and rejected: single decisions all scalar, tree walks in form A with shadows, 2^24 in an SGPR
     {"MILZMA_GEN_SYM_M0": "0", "MILZMA_GEN_SHADOW": "4"}, {"MILZMA_GEN_S1": "single"}, {"MILZMA_GEN_FORMB": "none", "MILZMA_GEN_FORMA2": "1"},
     {"MILZMA_GEN_K24S": "1"},
-    # round 6: the direct-bit chains on the vector ALU
-    {"MILZMA_GEN_VDIRECT": "1"}], ids=lambda k: "+".join(sorted(x[11:] for x in k)))
-def test_emulated_loop_under_measured_and_rejected_knobs(knobs):
+    # round 6: the direct-bit chains on the vector ALU, all bits / all but the last four of a chain
+    {"MILZMA_GEN_VDIRECT": "1"}, {"MILZMA_GEN_VDIRECT": "1", "MILZMA_GEN_VDIRECT_S": "4"}]
+
+
+def _knob_id(k):
+    return "+".join(sorted(x[11:] for x in k))
+
+
+@pytest.fixture(scope="module")
+def knob_runs():
+    """one process per knob set (the generator reads its switches at import), four at a time; each test waits for its own"""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=4)
+    jobs = {}
+    for knobs in KNOB_SETS:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_GEN_")}
+        env.update(knobs)
+        jobs[_knob_id(knobs)] = pool.submit(subprocess.run, [sys.executable, "-c", _KNOB_SCRIPT % {"root": ROOT}], env=env, capture_output=True,
+                                            text=True, timeout=900)
+    yield jobs
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
+@pytest.mark.parametrize("knobs", KNOB_SETS, ids=_knob_id)
+def test_emulated_loop_under_measured_and_rejected_knobs(knob_runs, knobs):
     """The generator switches of round 4's A/Bs (profiles/r04_kernel_ab.txt sections 3-4: scalar bookkeeping in shadows, the two deferred
     tree updates, range >> 11 on the scalar ALU; and the loop WITHOUT the batch that shipped) still generate loops that decode bit-exactly:
     what the profile says was measured can be rebuilt and measured again.  (The generator reads its switches at import: a process each.)"""
-    import subprocess
-    env = {k: v for k, v in os.environ.items() if not k.startswith("MILZMA_GEN_")}
-    env.update(knobs)
-    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    r = knob_runs[_knob_id(knobs)].result()
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
