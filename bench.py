@@ -340,7 +340,9 @@ def issue_roofline(config, kind, out_bytes, k_ms, khash, units=4096):
                               "instruction per 4.1 cycles (= one per cycle per CU); a never-taken branch behind its compare +1.7",
             "note": "busy = waves per SIMD x pipe cycles per byte / cycles per byte.  Both pipes of every SIMD are busy for most of the launch: the "
                     "kernel is bound by instruction issue, and what is left is the arbitration loss of four in-order waves per SIMD (a fifth wave "
-                    "adds 2.9 %, DESIGN.md section 4).  Instruction counts: exact, the kernel's symbol loop executed in tools/emu on 16 streams "
+                    "adds 2.9 %, DESIGN.md section 4): two pipes and N in-order waves are a closed queueing network whose servers are N / (N + 1) = "
+                    "80 % busy at balance, and the kernel's time follows the total of pipe cycles per byte, not the busier pipe (measured: "
+                    "profiles/r06_kernel_ab.txt section 3).  Instruction counts: exact, the kernel's symbol loop executed in tools/emu on 16 streams "
                     "of this workload (" + os.path.basename(mix_path) + "); prices: profiles/r05_pipe_prices.json"}
 
 
