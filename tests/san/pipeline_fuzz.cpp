@@ -556,6 +556,98 @@ bool streams_api(milzma_ctx* ctx, const std::vector<Case>& lzma_pool, size_t cop
   return ok;
 }
 
+// 3f. the push-mode calls under fault injection: open, four writes (every stream a quarter of its file per call), finish, close -- the n-th
+// fallible runtime call of the sequence fails.  Whatever fails: a call that reports MILZMA_OK for a stream delivered what the oracle has, an
+// infrastructure error carries a text, close and destroy release everything (the result buffers the waves deliver into, the slab, the
+// staging: LeakSanitizer), nothing crashes or hangs.  copies: as in streams_api (>= 64 streams: the delivering path).
+bool streams_faults(const std::vector<Case>& lzma_pool, long upto, long stride, size_t copies, long* infra_seen, long* good_seen, long* worst) {
+  std::vector<const Case*> files;
+  std::vector<orc_result> want;
+  for (size_t rep = 0; rep < copies; rep++)
+    for (const Case& c : lzma_pool) {
+      if (files.size() >= 12 * copies) break;
+      orc_result w;
+      memset(&w, 0, sizeof w);
+      orc_lzma_decompress(ptr_of(c.data), c.data.size(), nullptr, &w);
+      if (w.kind != ORC_OK || c.data.size() < 120 || w.in_consumed != c.data.size()) {
+        orc_free(w.out);
+        continue;
+      }
+      files.push_back(&c);
+      want.push_back(w);
+    }
+  bool ok = files.size() >= 3;
+  const uint32_t n = uint32_t(files.size());
+  long last = upto;
+  for (long f = 0; ok && f <= last; f += (f == 0 ? 1 : stride)) {
+    milzma_ctx* c = nullptr;
+    fake_hip_fail_at(f == 0 ? -1 : f);
+    if (milzma_create(0, &c) != MILZMA_OK) continue;
+    milzma_streams* S = nullptr;
+    bool infra = milzma_streams_open(c, MILZMA_KIND_RAW_LZMA, n, nullptr, &S) != MILZMA_OK;
+    if (infra && milzma_last_error(c)[0] == 0) {
+      printf("MISMATCH streams fault %ld: open failed without a text\n", f);
+      ok = false;
+    }
+    for (int q = 0; ok && !infra && q < 4; q++) {
+      std::vector<uint32_t> idx(n);
+      std::vector<const void*> data(n);
+      std::vector<size_t> len(n);
+      for (uint32_t i = 0; i < n; i++) {
+        const size_t total = files[i]->data.size(), a = total * size_t(q) / 4, b = q == 3 ? total : total * size_t(q + 1) / 4;
+        idx[i] = i;
+        data[i] = ptr_of(files[i]->data) + a;
+        len[i] = b - a;
+      }
+      std::vector<int32_t> st(n, -1);
+      if (milzma_streams_write(S, n, idx.data(), data.data(), len.data(), st.data()) != MILZMA_OK) {
+        infra = true;
+        if (milzma_streams_last_error(S)[0] == 0) {
+          printf("MISMATCH streams fault %ld: write %d failed without a text\n", f, q);
+          ok = false;
+        }
+      }
+    }
+    if (ok && S) {   // finish whatever became of the writes: a stream it calls decoded IS decoded
+      std::vector<milzma_output> outs(n);
+      for (milzma_output& o : outs) memset(&o, 0, sizeof o);
+      const int rc = milzma_streams_finish(S, outs.data());
+      for (uint32_t i = 0; i < n && ok; i++) {
+        const milzma_output& o = outs[i];
+        if (o.kind == MILZMA_OK && !infra && rc != MILZMA_INFRA_ERROR) {
+          (*good_seen)++;
+          g_compared++;
+          if (o.len != want[i].out_len || (o.len && memcmp(o.data, want[i].out, o.len) != 0) || o.in_consumed != files[i]->data.size()) {
+            printf("MISMATCH streams fault %ld: stream %u (%s) decoded to %zu bytes (want %zu)\n", f, i, files[i]->name.c_str(), o.len, want[i].out_len);
+            ok = false;
+          }
+        } else if (o.kind == MILZMA_OK) {   // (decoded although a call before it failed: then it must still be right -- or empty-handed)
+          if (o.len == want[i].out_len && (!o.len || memcmp(o.data, want[i].out, o.len) == 0)) (*good_seen)++;
+          else (*infra_seen)++;
+        } else {
+          (*infra_seen)++;
+        }
+      }
+      for (milzma_output& o : outs) milzma_free(o.data);
+    } else if (infra) {
+      (*infra_seen) += n;
+    }
+    *worst = std::max(*worst, fake_hip_calls());
+    if (f == 0) {
+      last = std::min(upto, fake_hip_calls() + 2);
+      if (infra) {
+        printf("MISMATCH streams fault run without a fault failed: %s\n", S ? milzma_streams_last_error(S) : milzma_last_error(c));
+        ok = false;
+      }
+    }
+    fake_hip_fail_at(-1);
+    if (S) milzma_streams_close(S);
+    milzma_destroy(c);
+  }
+  for (orc_result& w : want) orc_free(w.out);
+  return ok;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -763,6 +855,14 @@ int main(int argc, char** argv) {
         }
         for (auto& w : want) orc_free(w.out);
       }
+    }
+    // ... and the push-mode calls: a dozen streams, and enough of them for the waves to deliver into the result buffers themselves
+    long stream_infra = 0, stream_good = 0;
+    if (!getenv("PIPELINE_FAULTS_MULTI")) {
+      if (!streams_faults(pool[LZMA], upto, stride, 1, &stream_infra, &stream_good, &worst)) return 1;
+      if (!streams_faults(pool[LZMA], upto, stride * 7, 6, &stream_infra, &stream_good, &worst)) return 1;   // (every seventh call: 72 streams a run)
+      infra_files += stream_infra;
+      good_files += stream_good;
     }
     const size_t pooled = milzma_pool_trim(0);
     if (pooled != 0) {

@@ -148,7 +148,7 @@ def runs(binaries, inputs):
         # (multi-two-devices: also the multi-device whole-file batch and the one-ingest-point unit call -- there fault injection found a
         #  launch still writing the caller's buffer after its failed call had returned: the wait half drains the device on every way out now)
         env.update(MATRIX.get(path, {"FAKE_HIP_DEVICES": "2", "PIPELINE_FAULTS_MULTI": "1"}))
-        env["PIPELINE_FAULTS"] = "120"
+        env["PIPELINE_FAULTS"] = "180"
         if san == "tsan":
             env["PIPELINE_FAULT_STRIDE"] = "3"     # (every third call: ThreadSanitizer's runs are the slow ones)
         start(("faults", san, path), [binaries[san], inputs, "1", "5"], env)
@@ -176,7 +176,9 @@ def test_host_pipeline_fault_injection(runs, san, path):
     """Every fallible runtime call of a batch -- allocations, copies, stream and event creation, kernel launches: about a hundred per call --
     fails once (tests/san/fake_hip.cpp: fake_hip_fail_at), one run per call and entry point.  Whatever fails, every file comes back either as
     the oracle has it or with an infrastructure error and a text; no crash, no hang (the waves' input-ready word is set on failed uploads
-    too), and LeakSanitizer finds nothing left behind (it found an event leaked by milzma_create's own failure path)."""
+    too), and LeakSanitizer finds nothing left behind (it found an event leaked by milzma_create's own failure path).  Round 6: the push-mode
+    calls too -- open, four writes, finish, close of a dozen streams and of enough streams for the waves to deliver into the result buffers
+    (about 170 fallible calls per sequence)."""
     # (ThreadSanitizer's run: a failed piece of the second upload used to leave the earlier pieces in flight -- writing the input buffer
     #  the files decoded on their own were about to use --, and a launch that could not be made a streamed one ran on input that was
     #  not there yet: both found here, both fixed)
@@ -184,6 +186,6 @@ def test_host_pipeline_fault_injection(runs, san, path):
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and "runtime error" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr, tail
     last = r.stdout.strip().splitlines()[-1]
-    assert last.startswith("ok faults=120"), tail
+    assert last.startswith("ok faults=180"), tail
     stats = dict(kv.split("=") for kv in last.replace("<=", "=").split()[1:])
     assert int(stats["files_with_infra_error"]) > 30 and int(stats["compared"]) > 150
