@@ -344,7 +344,9 @@ KNOB_SETS = [
     {"MILZMA_GEN_SYM_M0": "0", "MILZMA_GEN_SHADOW": "4"}, {"MILZMA_GEN_S1": "single"}, {"MILZMA_GEN_FORMB": "none", "MILZMA_GEN_FORMA2": "1"},
     {"MILZMA_GEN_K24S": "1"},
     # round 6: the direct-bit chains on the vector ALU, all bits / all but the last four of a chain
-    {"MILZMA_GEN_VDIRECT": "1"}, {"MILZMA_GEN_VDIRECT": "1", "MILZMA_GEN_VDIRECT_S": "4"}]
+    {"MILZMA_GEN_VDIRECT": "1"}, {"MILZMA_GEN_VDIRECT": "1", "MILZMA_GEN_VDIRECT_S": "4"},
+    # ... and the loop without the quotient blocks (round 6's kernel up to hash 5f7ed0723658b699), and with them from five bits on only
+    {"MILZMA_GEN_QDIRECT": "0"}, {"MILZMA_GEN_QDIRECT": "5"}]
 
 
 def _knob_id(k):

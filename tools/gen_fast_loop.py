@@ -195,6 +195,15 @@ K24S = os.environ.get("MILZMA_GEN_K24S", "0") == "1"
 #       VDIRECT_S: the LAST so many bits of every chain stay on the scalar ALU (the pipes' loads meet somewhere in between): the chain then crosses
 #       from the vector registers to (range, code, t4) in front of them, else at its end.
 VDIRECT = os.environ.get("MILZMA_GEN_VDIRECT", "0") == "1"
+#   QDIRECT = j0 (round 6; 0 = off): behind a normalisation inside a direct-bit chain the range is r << 8 and the next bits are floor(code / (range >> j))
+#       EXACTLY while code < range (get_bit's halvings shift out zeros only) -- j = min(bits up to the next normalisation or the chain's end, 6) of them at once
+#       when j >= j0: lane L tests the candidate c = (2^j - 1 - L) & (2^j - 1), code - c * (range >> j) < (range >> j) (no product wraps: c < 2^j,
+#       range >> j < 2^(32 - j)); the first lane that answers IS the inverted quotient the accumulator wants; no lane answers when code >= range (a damaged
+#       stream): then the serial bits run.  7 scalar + 4 .. 5 vector instructions and 2 + 2 branches against 4 j scalar ones -- and a chain of one's own that is
+#       shorter by more than the count says (four dependent scalar instructions per serial bit).  The block lives out of line; every normalisation block of the
+#       chains carries one more instruction (the branch to it, or s_nop): the entry arithmetic stays as it is.
+#       Measured (profiles/r06_kernel_ab.txt section 6): from 5 / 4 / 3 / 2 bits on -1.2 / -1.5 / -1.75 / -1.7 % at dict 64 KiB, -2.6 % at 8 MiB.  3 ships.
+QDIRECT = int(os.environ.get("MILZMA_GEN_QDIRECT", "3"))
 VDIRECT_S = int(os.environ.get("MILZMA_GEN_VDIRECT_S", "0"))
 VBASE = int(os.environ.get("MILZMA_GEN_VBASE", "64"))
 # Where the loop's code falls in the 32-byte instruction fetch lines is worth +-1.2 % (round 5, profiles/r05_kernel_ab.txt section 4: the loop 64-byte
@@ -235,6 +244,7 @@ if STATE_TBL:
 #  it is used: one vector instruction per match)
 DISP2 = DISP2 and DISPMAD and DIRECT8
 VDIRECT = VDIRECT and DISP2 and NBPRE
+QDIRECT = QDIRECT if (DISP2 and NBPRE and not VDIRECT) else 0
 VB2_INLINE = DISP2 and not NORM_S >= {"tree", "single", "lit", "direct"}
 V, MROW, PS0, PS0M2, CLOBBER_V, LIT_REGS = {}, "", "", "", [], 16
 LIT0, LIT1 = "v%d" % VBASE, "v%d" % (VBASE + 1)   # literal plain table: 2 dwords per row from v64 (fixed, indexed with s_set_gpr_idx)
@@ -851,7 +861,7 @@ class Gen:
             self.norm(kind="direct")
 
     @role("normstub")
-    def direct_norm(self, mark=None, vec=False):
+    def direct_norm(self, mark=None, vec=False, slot=None):
         """RangeDecoder::normalize (rangecoder.rs:59-69), unconditional and inline: range < 2^24 is known here"""
         e, L = self.e, self.L
         k = self.new("DN")
@@ -880,13 +890,43 @@ class Gen:
         if not OFFBIAS:
             e("s_bitcmp1_b32 {off}, 6")
         e("s_cbranch_scc1 " + L(k))
-        if mark:
-            self.lab(mark + "_e")
         self.lab(k + "r")
+        if slot:                                 # (QDIRECT: one more instruction per normalisation block -- the way to the quotient block, or s_nop)
+            e(slot)
+        if mark and not self.reach:
+            self.cur.append("L%s%%=:" % (mark + "_e"))   # (behind an unconditional branch: a mark for the block's size, nothing arrives here)
+        elif mark:
+            self.lab(mark + "_e")
         with Gen._Into(self, self.stubs):
             self.lab(k)
             e("s_call_b64 " + RET + ", " + L("refill"))
             e("s_branch " + L(k + "r"))
+
+    @role("core")
+    def direct_quotient(self, name, j, cont, serial):
+        """QDIRECT: j direct bits at once, out of line; cont: where the chain goes on behind them, serial: the bit block that does them one by one"""
+        e, L = self.e, self.L
+        m = (1 << j) - 1
+        with Gen._Into(self, self.stubs):
+            self.lab(name)
+            e("s_lshr_b32 {range}, {range}, %d" % j)
+            e("v_xor_b32 {vx}, %d, {v_lane}" % m)
+            if j < 6:
+                e("v_and_b32 {vx}, %d, {vx}" % m)
+            e("v_mul_lo_u32 {vx}, {vx}, {range}")
+            e("v_sub_u32 {vx}, {code}, {vx}")
+            e("v_cmp_gt_u32 vcc, {range}, {vx}")
+            e("s_cbranch_vccz " + L(name + "f"))
+            e("s_ff1_i32_b64 {t0}, vcc")                 # the inverted quotient
+            e("s_xor_b32 {t1}, {t0}, %d" % m)
+            e("s_mul_i32 {t1}, {t1}, {range}")
+            e("s_sub_u32 {code}, {code}, {t1}")
+            e("s_lshl_b32 {t4}, {t4}, %d" % j)
+            e("s_or_b32 {t4}, {t4}, {t0}")
+            e("s_branch " + L(cont))
+            self.lab(name + "f")                         # code >= range: bit by bit, as get_bit has it
+            e("s_lshl_b32 {range}, {range}, %d" % j)
+            e("s_branch " + L(serial))
 
     @role("book")
     def direct_cross(self):
@@ -1490,6 +1530,8 @@ class Gen:
                 e("v_mov_b32 {vr}, {range}")
                 e("v_mov_b32 {vb}, {code}")
                 e("v_mov_b32 {va}, 0")
+            if QDIRECT:
+                assert not any(x[2] for x in self.q)             # (nothing queued reads vcc: the quotient blocks use it)
             if not VDIRECT or VDIRECT_S:
                 e("s_mov_b32 {t4}, 0")
             e("v_readlane_b32 {t2}, {tbl_a}, {sym}")
@@ -1531,17 +1573,29 @@ class Gen:
             for v in range(8):
                 lab("dchain%d" % v)
                 if v >= 2:                                   # (every chain carries four normalisation blocks, so that they are all
-                    self.direct_norm(vec=VDIRECT)            #  the same size: this one is never reached)
+                    self.direct_norm(vec=VDIRECT, slot="s_nop 0" if QDIRECT else None)   # the same size: this one is never reached)
                 for r in range(25, -1, -1):                  # r = direct bits left after this one
                     mark = v == 0 and r == 25
                     vec = VDIRECT and r >= VDIRECT_S
+                    if QDIRECT:
+                        lab("dq%d_%d" % (v, r))              # (a quotient block's way back, or its serial fall-back)
                     if mark:
                         lab("db_s")
                     self.direct_bit(R("t4"), test=False, vec=vec)
                     if mark:
                         lab("db_e")
                     if r % 8 == v:
-                        self.direct_norm(mark="dn" if (v == 0 and r == 24) else None, vec=vec)
+                        slot = None
+                        if QDIRECT:
+                            j = min(r, 8, 6)                 # bits up to the next normalisation (or the chain's end), six at most at once
+                            if j >= QDIRECT:
+                                qn = "dQ%d_%d" % (v, r)
+                                slot = "s_branch " + L(qn)
+                            else:
+                                slot = "s_nop 0"
+                        self.direct_norm(mark="dn" if (v == 0 and r == 24) else None, vec=vec, slot=slot)
+                        if QDIRECT and slot != "s_nop 0":
+                            self.direct_quotient(qn, j, "dq%d_%d" % (v, r - j - 1) if r - j - 1 >= 0 else "direct_done", "dq%d_%d" % (v, r - 1))   # (the chain's end: straight on, not by its trampoline)
                     if VDIRECT and VDIRECT_S and r == VDIRECT_S:
                         if v == 0:
                             lab("dt_s")
