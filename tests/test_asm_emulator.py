@@ -376,3 +376,43 @@ def test_emulated_loop_under_measured_and_rejected_knobs(knob_runs, knobs):
     what the profile says was measured can be rebuilt and measured again.  (The generator reads its switches at import: a process each.)"""
     r = knob_runs[_knob_id(knobs)].result()
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_quotient_block_arithmetic_against_get_bit():
+    """The quotient blocks of the direct-bit chains (tools/gen_fast_loop.py: QDIRECT, Gen.direct_quotient) in numpy, against RangeDecoder::get_bit
+    (rangecoder.rs:71-82) bit by bit: behind a normalisation the range is r << 8; for every j = 2 .. 6, ranges of that form and codes below, at and above
+    the range (a damaged stream can get there: a direct bit on an odd range leaves code == range), and at every multiple of range >> j and its
+    neighbours: a lane answers exactly when code < range, then code, range and the inverted bits are what j serial bits leave; no lane answers otherwise
+    (the block then runs the serial bits)."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    for j in range(2, 7):
+        m = (1 << j) - 1
+        n = 200000
+        R = (rng.integers(1 << 16, 1 << 24, n, dtype=np.uint64) << np.uint64(8)).astype(np.uint64)      # normalised: [2^24, 2^32), low byte zero
+        code = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+        r = R >> np.uint64(j)
+        k = rng.integers(0, 1 << j, n, dtype=np.uint64)
+        edge = (k * r + rng.integers(-2, 3, n).astype(np.int64).astype(np.uint64)) & np.uint64(0xFFFFFFFF)
+        pick = rng.integers(0, 4, n)
+        code = np.where(pick == 0, edge, np.where(pick == 1, code % R, np.where(pick == 2, R + (code & np.uint64(3)), code)))
+        # serial: j times get_bit; acc = 2 acc + (code < range) as the loop accumulates it (the inverted bit)
+        sr, sc, acc = R.copy(), code.copy(), np.zeros(n, dtype=np.uint64)
+        for _ in range(j):
+            sr = sr >> np.uint64(1)
+            lt = sc < sr
+            sc = np.where(lt, sc, sc - sr)
+            acc = (acc << np.uint64(1)) | lt.astype(np.uint64)
+        # the block: 64 lanes, candidate c = (m - L) & m, 32-bit wrapping arithmetic
+        lanes = np.arange(64, dtype=np.uint64)
+        c = (np.uint64(m) ^ lanes) & np.uint64(m)
+        prod = (c[None, :] * r[:, None]) & np.uint64(0xFFFFFFFF)
+        diff = (code[:, None] - prod) & np.uint64(0xFFFFFFFF)
+        ans = diff < r[:, None]
+        any_lane = ans.any(axis=1)
+        first = ans.argmax(axis=1).astype(np.uint64)
+        assert (any_lane == (code < R)).all(), j
+        q = first ^ np.uint64(m)
+        qc = (code - q * r) & np.uint64(0xFFFFFFFF)
+        ok = any_lane
+        assert (qc[ok] == sc[ok]).all() and (r[ok] == sr[ok]).all() and (first[ok] == acc[ok]).all(), j
