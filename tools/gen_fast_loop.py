@@ -199,8 +199,7 @@ VDIRECT = os.environ.get("MILZMA_GEN_VDIRECT", "0") == "1"
 #       EXACTLY while code < range (get_bit's halvings shift out zeros only) -- j = min(bits up to the next normalisation or the chain's end, 6) of them at once
 #       when j >= j0: lane L tests the candidate c = (2^j - 1 - L) & (2^j - 1), code - c * (range >> j) < (range >> j) (no product wraps: c < 2^j,
 #       range >> j < 2^(32 - j)); the first lane that answers IS the inverted quotient the accumulator wants; no lane answers when code >= range (a damaged
-#       stream): then the serial bits run.  7 scalar + 4 .. 5 vector instructions and 2 + 2 branches against 4 j scalar ones -- and a chain of one's own that is
-#       shorter by more than the count says (four dependent scalar instructions per serial bit).  The block lives out of line; every normalisation block of the
+#       stream): then the serial bits run.  7 scalar + 4 .. 5 vector instructions and 2 + 2 branches against 4 j scalar ones.  The block lives out of line; every normalisation block of the
 #       chains carries one more instruction (the branch to it, or s_nop): the entry arithmetic stays as it is.
 #       Measured (profiles/r06_kernel_ab.txt section 6): from 5 / 4 / 3 / 2 bits on -1.2 / -1.5 / -1.75 / -1.7 % at dict 64 KiB, -2.6 % at 8 MiB.  3 ships.
 QDIRECT = int(os.environ.get("MILZMA_GEN_QDIRECT", "3"))
