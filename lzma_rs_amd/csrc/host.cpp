@@ -301,6 +301,21 @@ OutPool& out_pool() {
   return p;
 }
 
+size_t out_live_buffers() {   // (how many result buffers callers hold right now: the sanitizer harness asks after every sequence)
+  OutPool& p = out_pool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  return p.live.size();
+}
+
+size_t out_pooled_buffers() {   // (buffers the pool holds: 0 after milzma_pool_trim(0))
+  OutPool& p = out_pool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  size_t n = 0;
+  for (auto* m : {&p.free_pinned, &p.free_by_cap})
+    for (auto& kv : *m) n += kv.second.size();
+  return n;
+}
+
 size_t out_class(size_t n) {  // capacity class: powers of two up to 64 KiB, multiples of 64 KiB above
   if (n <= 4096) return 4096;
   if (n <= (size_t(1) << 16)) {
@@ -496,7 +511,8 @@ bool ensure_progress(milzma_ctx* ctx) {
   }
   (void)hipGetLastError();
   if (hp) (void)hipHostFree(hp);
-  return false;
+  ctx->err = "hipHostMalloc: no page-locked memory for the span counters";   // (a caller that gives up on this says why: the sanitizer harness's
+  return false;                                                                //  push-mode fault injection found a write failing without a text)
 }
 
 // Launches `order` (unit indices) in class `cls`; kernel time is accumulated into ctx.

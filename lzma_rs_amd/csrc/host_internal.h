@@ -212,6 +212,8 @@ void pin_release(PinBuf& b);
 unsigned host_threads();
 size_t out_class(size_t n);
 uint8_t* out_alloc(size_t n, bool pinned = false);
+size_t out_live_buffers();
+size_t out_pooled_buffers();
 bool out_alloc_many(const size_t* n, size_t count, bool pinned, uint8_t** out);   // (thousands at once: one lock, not two per buffer)
 LitClass classify(const milzma_ctx* ctx, const milzma_unit& u);
 bool ensure_progress(milzma_ctx* ctx);

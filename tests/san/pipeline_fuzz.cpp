@@ -8,6 +8,11 @@
 //
 // Which paths a run takes is a matter of the environment (MILZMA_STREAM_MIN, MILZMA_PINNED_OUT, MILZMA_TWO_PART, MILZMA_STREAM,
 // FAKE_HIP_DEVICES, ...): the test runs the matrix.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/lsan_interface.h>
+#endif
+#endif
 #include <dirent.h>
 
 #include <cinttypes>
@@ -20,6 +25,8 @@
 
 #include "lzma_oracle.h"
 #include "milzma.h"
+
+namespace milzma { namespace host { size_t out_live_buffers(); size_t out_pooled_buffers(); } }   // (lzma_rs_amd/csrc/host.cpp, linked in: result buffers callers hold right now)
 
 void fake_hip_fail_at(long n);   // tests/san/fake_hip.cpp: the n-th fallible runtime call from now on fails (-1: none)
 long fake_hip_calls();
@@ -643,6 +650,21 @@ bool streams_faults(const std::vector<Case>& lzma_pool, long upto, long stride, 
     fake_hip_fail_at(-1);
     if (S) milzma_streams_close(S);
     milzma_destroy(c);
+    if (milzma::host::out_live_buffers() != 0) {   // every result buffer of the sequence has been freed or was never handed out
+      printf("MISMATCH streams fault %ld (%u streams): %zu result buffers are still held after finish, free and close\n", f, n, milzma::host::out_live_buffers());
+      ok = false;
+    }
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+    if (getenv("PIPELINE_LEAK_EACH")) {   // (debugging aid: which fault leaves something behind)
+      if (!strcmp(getenv("PIPELINE_LEAK_EACH"), "trim")) milzma_pool_trim(0);
+      if (__lsan_do_recoverable_leak_check()) {
+        printf("LEAK after the push-mode sequence with fault %ld (%u streams, infra %d)\n", f, n, int(infra));
+        ok = false;
+      }
+    }
+#endif
+#endif
   }
   for (orc_result& w : want) orc_free(w.out);
   return ok;
@@ -651,6 +673,7 @@ bool streams_faults(const std::vector<Case>& lzma_pool, long upto, long stride, 
 }  // namespace
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IOLBF, 0);   // (LeakSanitizer leaves through _exit: what was printed must be out by then)
   if (argc < 4) {
     fprintf(stderr, "usage: pipeline_fuzz <dir> <rounds> <rng seed>\n");
     return 2;
@@ -858,15 +881,16 @@ int main(int argc, char** argv) {
     }
     // ... and the push-mode calls: a dozen streams, and enough of them for the waves to deliver into the result buffers themselves
     long stream_infra = 0, stream_good = 0;
-    if (!getenv("PIPELINE_FAULTS_MULTI")) {
+    if (!getenv("PIPELINE_FAULTS_MULTI") && !getenv("PIPELINE_NO_STREAM_FAULTS")) {
       if (!streams_faults(pool[LZMA], upto, stride, 1, &stream_infra, &stream_good, &worst)) return 1;
       if (!streams_faults(pool[LZMA], upto, stride * 7, 6, &stream_infra, &stream_good, &worst)) return 1;   // (every seventh call: 72 streams a run)
       infra_files += stream_infra;
       good_files += stream_good;
     }
     const size_t pooled = milzma_pool_trim(0);
-    if (pooled != 0) {
-      printf("MISMATCH: %zu bytes still pooled after milzma_pool_trim(0)\n", pooled);
+    if (pooled != 0 || milzma::host::out_pooled_buffers() != 0 || milzma::host::out_live_buffers() != 0) {
+      printf("MISMATCH: %zu bytes / %zu buffers still pooled after milzma_pool_trim(0), %zu still held by callers\n", pooled, milzma::host::out_pooled_buffers(),
+             milzma::host::out_live_buffers());
       return 1;
     }
     printf("ok faults=%ld calls_per_batch<=%ld files_with_infra_error=%ld files_decoded=%ld compared=%" PRIu64 "\n", upto, worst, infra_files, good_files, g_compared);
